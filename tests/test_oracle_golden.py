@@ -1,0 +1,236 @@
+"""Pin the oracle (and the vectorised mesh constructor) to outputs of the reference.
+
+The `.npz` fixtures were produced by running py-tdgl v0.8.3 itself
+(`tests/golden/generate_golden.py`).  The oracle makes the same SciPy/NumPy calls in the
+same order, so agreement is expected at round-off level; tolerances are written per test.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import (
+    GAMMA_DEFAULT,
+    U_DEFAULT,
+    align_phase,
+    coo_sorted,
+    edge_terminal,
+    max_abs,
+    mesh_from_golden,
+    options_from_golden,
+    reference_mesh,
+    remove_mean,
+    synthetic_mesh,
+    uniform_field_A,
+)
+from oracle import FVOperators, OracleSolver, psi_update, run_time_loop
+
+
+# ---------------------------------------------------------------- mesh construction
+@pytest.mark.parametrize("name", ["mesh_small", "mesh_strip", "mesh_irregular"])
+def test_vectorised_mesh_matches_reference(name):
+    g = load_golden(name)
+    mesh = mesh_from_golden(g)
+    em = mesh.edge_mesh
+    # integer structure: exact
+    assert np.array_equal(em.edges, g["mesh_edges"])
+    assert np.array_equal(em.boundary_edge_indices, g["mesh_boundary_edge_indices"])
+    assert np.array_equal(mesh.boundary_indices, g["mesh_boundary_indices"])
+    # geometry: same formulas -> a few ulp
+    assert max_abs(em.centers, g["mesh_centers"]) == 0
+    assert max_abs(em.directions, g["mesh_directions"]) == 0
+    assert max_abs(em.edge_lengths, g["mesh_edge_lengths"]) < 1e-15
+    assert max_abs(mesh.dual_sites, g["mesh_dual_sites"]) < 1e-13
+    assert max_abs(em.dual_edge_lengths, g["mesh_dual_edge_lengths"]) < 1e-13
+    # Voronoi areas: reference = per-site ConvexHull, here = signed kites
+    assert max_abs(mesh.areas, g["mesh_areas"]) < 1e-13 * max(1.0, g["mesh_areas"].max())
+
+
+def test_synthetic_generator_is_the_survey_recipe():
+    # L=70 -> 5,791 sites / 17,070 edges
+    mesh = synthetic_mesh(70)
+    assert len(mesh.sites) == 5791
+    assert len(mesh.edge_mesh.edges) == 17070
+    g = load_golden("traj_zero_field_5k")
+    assert np.array_equal(mesh.sites, g["sites"])
+    assert np.array_equal(mesh.elements, g["elements"])
+
+
+# ---------------------------------------------------------------- operators
+def _assert_coo(mat, g, prefix, tol=1e-14):
+    r, c, v = coo_sorted(mat)
+    assert tuple(mat.shape) == tuple(g[prefix + "_shape"])
+    assert np.array_equal(r, g[prefix + "_row"])
+    assert np.array_equal(c, g[prefix + "_col"])
+    scale = max(1.0, np.abs(g[prefix + "_val"]).max())
+    assert max_abs(v, g[prefix + "_val"]) <= tol * scale
+
+
+def test_operator_entries_match_reference():
+    g = load_golden("operators_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    ops = FVOperators(mesh, fixed_sites=g["fixed_sites"], fix_psi=True)
+    ops.build_operators()
+    ops.set_link_exponents(g["A"])
+    _assert_coo(ops.psi_laplacian, g, "fixed_psi_laplacian")
+    _assert_coo(ops.psi_gradient, g, "psi_gradient")
+    _assert_coo(ops.divergence, g, "divergence")
+    _assert_coo(ops.mu_laplacian, g, "mu_laplacian")
+    _assert_coo(ops.mu_boundary_laplacian, g, "mu_boundary_laplacian")
+    _assert_coo(ops.mu_gradient, g, "mu_gradient")
+    assert max_abs(ops.get_supercurrent(g["psi"]), g["supercurrent"]) < 1e-14
+    # the reference's in-place update path for a new A gives what a rebuild gives
+    ops.set_link_exponents(g["A2"])
+    _assert_coo(ops.psi_laplacian, g, "fixed_psi_laplacian_A2")
+    _assert_coo(ops.psi_gradient, g, "psi_gradient_A2")
+    free = FVOperators(mesh, fixed_sites=g["fixed_sites"], fix_psi=False)
+    free.build_operators()
+    free.set_link_exponents(g["A"])
+    _assert_coo(free.psi_laplacian, g, "free_psi_laplacian")
+
+
+# ---------------------------------------------------------------- single psi update
+def test_psi_update_matches_reference_including_failures():
+    g = load_golden("psi_update_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    ops = FVOperators(mesh, fixed_sites=g["fixed_sites"], fix_psi=True)
+    ops.build_operators()
+    ops.set_link_exponents(g["A"])
+    psi = g["psi"]
+    assert not g["ok"].all() and g["ok"].any()  # fixture holds both outcomes
+    for k, dt in enumerate(g["dts"]):
+        res = psi_update(
+            psi, np.abs(psi) ** 2, g["mu"], g["epsilon"], float(g["gamma"]), float(g["u"]),
+            float(dt), ops.psi_laplacian,
+        )
+        assert (res is not None) == bool(g["ok"][k])
+        if res is not None:
+            assert max_abs(res[0], g[f"out{k}_psi"]) < 1e-14
+            assert max_abs(res[1], g[f"out{k}_abs_sq"]) < 1e-14
+
+
+# ---------------------------------------------------------------- trajectories
+def _run_case(g, mesh, b, terminals=(), current_func=None, epsilon=1.0, **opt_override):
+    opts = options_from_golden(g, **opt_override)
+    probes = [int(p) for p in g["probe_points"]] if "probe_points" in g else None
+    solver = OracleSolver(
+        mesh, uniform_field_A(mesh, b), epsilon, U_DEFAULT, GAMMA_DEFAULT, opts,
+        terminals=terminals, current_func=current_func, probe_points=probes,
+    )
+    out = run_time_loop(solver, opts)
+    return solver, out
+
+
+def _assert_trajectory(g, mesh, out, tol):
+    log = out["log"]
+    dts = log.array("dt")
+    assert len(dts) == len(g["call_dt"]) == out["book"]["calls"]
+    assert max_abs(dts, g["call_dt"]) <= tol * g["call_dt"].max()
+    # gauge-invariant fields
+    assert max_abs(np.abs(out["psi"]) ** 2, np.abs(g["final_psi"]) ** 2) < tol
+    assert max_abs(out["supercurrent"], g["final_supercurrent"]) < tol
+    assert max_abs(out["normal_current"], g["final_normal_current"]) < tol
+    scale = max(1.0, np.abs(remove_mean(g["final_mu"])).max())
+    assert max_abs(remove_mean(out["mu"]), remove_mean(g["final_mu"])) < tol * scale
+    assert max_abs(align_phase(out["psi"], g["final_psi"]), g["final_psi"]) < tol
+    if "call_mu_probe" in g:
+        mu_p, th_p = log.array("mu"), log.array("theta")
+        if mu_p.shape[1] > 1:  # voltage between probes is gauge invariant
+            assert max_abs(mu_p[:, 0] - mu_p[:, 1], g["call_mu_probe"][:, 0] - g["call_mu_probe"][:, 1]) < tol * scale
+            d1 = np.angle(np.exp(1j * (th_p[:, 0] - th_p[:, 1])))
+            d2 = np.angle(np.exp(1j * (g["call_theta_probe"][:, 0] - g["call_theta_probe"][:, 1])))
+            assert max_abs(np.exp(1j * d1), np.exp(1j * d2)) < tol
+
+
+def test_trajectory_zero_field_5k_config1():
+    g = load_golden("traj_zero_field_5k")
+    mesh = synthetic_mesh(70)
+    _, out = _run_case(g, mesh, 0.0)
+    _assert_trajectory(g, mesh, out, 1e-12)
+    assert np.allclose(np.abs(out["psi"]), 1.0, atol=1e-12)  # psi = 1 is stationary
+
+
+def test_trajectory_uniform_field_vortex_entry():
+    g = load_golden("traj_field_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    _, out = _run_case(g, mesh, float(g["b"]))
+    _assert_trajectory(g, mesh, out, 1e-12)
+    assert (np.abs(out["psi"]) ** 2).min() < 0.05  # vortex cores are present
+
+
+def test_trajectory_fixed_dt():
+    g = load_golden("traj_field_small_fixed_dt")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    _, out = _run_case(g, mesh, float(g["b"]))
+    _assert_trajectory(g, mesh, out, 1e-12)
+    assert np.all(out["log"].array("dt") == float(g["opt_dt_init"]))
+
+
+def test_trajectory_transport_with_terminals_and_thermalisation():
+    g = load_golden("traj_transport_strip")
+    mesh = reference_mesh(load_golden("mesh_strip"))
+    terms = [edge_terminal(mesh, "source", -30.0), edge_terminal(mesh, "drain", 30.0)]
+    for t in terms:  # terminal detection agrees with the fixture
+        assert np.array_equal(t["site_indices"], g[f"term_{t['name']}_sites"])
+        assert np.array_equal(t["boundary_edge_indices"], g[f"term_{t['name']}_boundary_pos"])
+        assert np.isclose(t["length"], float(g[f"term_{t['name']}_length"]), rtol=1e-14)
+    cur = float(g["current"])
+    solver, out = _run_case(
+        g, mesh, float(g["b"]), terminals=terms,
+        current_func=lambda t: {"source": cur, "drain": -cur},
+    )
+    assert max_abs(solver.mu_boundary, g["mu_boundary"]) < 1e-15
+    # thermalisation steps are taken but not logged by run_time_loop
+    n_sim = int((g["call_time"] == 0).nonzero()[0][-1])  # first call of "Simulating"
+    sim = {k: (v[n_sim:] if k.startswith("call_") else v) for k, v in g.items()}
+    assert out["book"]["calls"] == len(g["call_dt"])
+    out["book"]["calls"] = len(sim["call_dt"])
+    _assert_trajectory(sim, mesh, out, 1e-12)
+    assert np.all(out["psi"][g["fixed_sites"]] == 0)
+
+
+def test_trajectory_time_dependent_current_free_terminal_psi():
+    g = load_golden("traj_transport_ramp")
+    mesh = reference_mesh(load_golden("mesh_strip"))
+    terms = [edge_terminal(mesh, "source", -30.0), edge_terminal(mesh, "drain", 30.0)]
+    ramp = lambda t: {"source": 0.5 * min(t, 8.0), "drain": -0.5 * min(t, 8.0)}  # noqa: E731
+    _, out = _run_case(g, mesh, 0.0, terminals=terms, current_func=ramp)
+    _assert_trajectory(g, mesh, out, 1e-12)
+
+
+def test_trajectory_with_dt_retries():
+    g = load_golden("traj_retry_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    _, out = _run_case(g, mesh, float(g["b"]))
+    assert g["call_dt"].min() < float(g["opt_dt_init"])  # the fixture really retried
+    _assert_trajectory(g, mesh, out, 1e-12)
+
+
+def test_retry_budget_exhaustion_raises_like_reference():
+    # non-adaptive: any failed update raises immediately (solver.py:478-483)
+    g = load_golden("traj_retry_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    with pytest.raises(RuntimeError, match="Solver failed to converge in 10 retries at step"):
+        _run_case(g, mesh, float(g["b"]), adaptive=False)
+
+
+# ---------------------------------------------------------------- loop bookkeeping
+def test_runner_bookkeeping_matches_reference():
+    g = load_golden("runner_bookkeeping")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    saves = []
+    opts = options_from_golden(g)
+    solver = OracleSolver(
+        mesh, uniform_field_A(mesh, float(g["b"])), 1.0, U_DEFAULT, GAMMA_DEFAULT, opts,
+        probe_points=[int(p) for p in g["probe_points"]],
+    )
+    out = run_time_loop(
+        solver, opts, on_save=lambda stage, i, t, dt, *fields: saves.append((i, t, dt))
+    )
+    assert out["book"]["calls"] == len(g["call_dt"])
+    assert [s[0] for s in saves] == list(g["save_step"])
+    assert max_abs([s[1] for s in saves], g["save_time"]) < 1e-12
+    assert max_abs([s[2] for s in saves], g["save_dt"]) < 1e-12
+    # one step past solve_time is taken; time is not advanced for it (runner.py:429-433)
+    assert out["book"]["stages"][-1][2] >= float(g["opt_solve_time"])
+    assert np.isclose(out["book"]["stages"][-1][2], float(g["final_runner_time"]), rtol=1e-12)
