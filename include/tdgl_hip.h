@@ -1,0 +1,203 @@
+/*
+ * tdgl_hip.h -- C-ABI of the MI355X-native TDGL time-stepping core (libtdgl_hip.so).
+ *
+ * The reference (loganbvh/py-tdgl v0.8.3) has no FFI: its hot path is the Python method
+ * seam TDGLSolver / MeshOperators.  Each entry point below names the reference interface
+ * it replaces (file:line under the reference tree).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - All arrays are caller-owned, C-contiguous host buffers, borrowed for the duration of
+ *     the call.  double = IEEE fp64; complex arrays are interleaved (re, im) pairs of
+ *     doubles (numpy complex128); indices are int32.
+ *   - Sites and edges are numbered as in the reference's Mesh / EdgeMesh
+ *     (tdgl/finite_volume/mesh.py:45-69, edge_mesh.py:25-42); the library applies its own
+ *     locality permutation internally and inverts it on every output.
+ *   - Every function returns a tdgl_status (0 = ok); tdgl_last_error() returns the message
+ *     of the most recent failure on that context (or globally for tdgl_create).
+ *   - One host thread per context; no re-entrancy.  Device buffers and the HIP stream are
+ *     owned by the context.
+ */
+#ifndef TDGL_HIP_H
+#define TDGL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tdgl_ctx tdgl_ctx;
+
+typedef enum {
+    TDGL_OK = 0,
+    TDGL_ERR_HIP = 1,          /* HIP runtime / RCCL failure */
+    TDGL_ERR_ARG = 2,          /* bad argument or call order */
+    TDGL_ERR_PSI_RETRIES = 3,  /* psi update failed after max_solve_retries (reference:
+                                  RuntimeError at tdgl/solver/solver.py:478-483) */
+    TDGL_ERR_PCG = 4,          /* Poisson solve did not reach the tolerance */
+    TDGL_ERR_NOT_READY = 5     /* hierarchy / link variables / state not set yet */
+} tdgl_status;
+
+/* Mesh description: the arrays of the reference's Mesh/EdgeMesh plus the boundary
+ * conditions MeshOperators is constructed with
+ * (tdgl/finite_volume/operators.py:245-280, tdgl/solver/solver.py:258-276). */
+typedef struct {
+    int64_t n_sites;
+    int64_t n_edges;
+    int64_t n_boundary_edges;
+    const int32_t *edges;                 /* [n_edges, 2], i < j, lexicographic        */
+    const double *areas;                  /* [n_sites]  Voronoi cell areas             */
+    const double *edge_lengths;           /* [n_edges]                                 */
+    const double *dual_edge_lengths;      /* [n_edges]                                 */
+    const double *directions;             /* [n_edges, 2]  r_j - r_i (un-normalised)   */
+    const int32_t *boundary_edge_indices; /* [n_boundary_edges] edge ids               */
+    const int32_t *fixed_sites;           /* [n_fixed] terminal sites (may be NULL)    */
+    int64_t n_fixed;
+    int32_t fix_psi;                      /* options.terminal_psi is not None          */
+    const int32_t *site_perm;             /* [n_sites] internal -> reference site id
+                                             (e.g. reverse Cuthill-McKee); NULL = identity */
+    double u;                             /* Layer.u      (tdgl/device/layer.py:30)    */
+    double gamma;                         /* Layer.gamma  (tdgl/device/layer.py:31)    */
+} tdgl_mesh_desc;
+
+/* One level of the algebraic-multigrid hierarchy that preconditions the mu solve
+ * (replaces the SuperLU factorisation of operators.py:305-308).  CSR, int32 indices, in
+ * the INTERNAL (permuted) site order for level 0.  P/R are NULL on the last level. */
+typedef struct {
+    int64_t n;            /* rows of A on this level                                   */
+    int64_t n_coarse;     /* rows of the next level (0 on the last level)              */
+    const int32_t *A_indptr;  const int32_t *A_indices;  const double *A_data;
+    const double *dinv;   /* [n] 1/diag(A)                                             */
+    double rho;           /* estimate of the spectral radius of D^-1 A                 */
+    const int32_t *P_indptr;  const int32_t *P_indices;  const double *P_data; /* n x n_coarse */
+    const int32_t *R_indptr;  const int32_t *R_indices;  const double *R_data; /* n_coarse x n */
+} tdgl_amg_level;
+
+/* Adaptive time-step controller = SolverOptions fields read by the step
+ * (tdgl/solver/options.py:66-73; used at solver.py:316-320, 475-485, 698-707). */
+typedef struct {
+    double dt_init;
+    double dt_max;
+    int32_t adaptive;
+    int32_t adaptive_window;
+    int32_t max_solve_retries;
+    double adaptive_time_step_multiplier;
+} tdgl_controller;
+
+typedef struct {
+    double rtol;          /* ||b - A mu||_2 <= rtol * ||b||_2                          */
+    int32_t max_iter;
+    int32_t nu;           /* Jacobi sweeps before and after the coarse correction      */
+    int32_t check_every;  /* host convergence checks every this many iterations        */
+    int32_t edge_currents_every_step; /* 1: J_s, J_n are formed every step like the
+                                         reference's update(); 0: only on tdgl_get_state */
+} tdgl_poisson_options;
+
+/* ------------------------------------------------------------------ lifetime */
+int tdgl_device_count(void);
+const char *tdgl_version(void);
+const char *tdgl_last_error(const tdgl_ctx *ctx); /* ctx may be NULL */
+
+/* Replaces MeshOperators.__init__ + build_operators() for the A-independent operators
+ * (operators.py:245-308): uploads the mesh, builds the SELL-64 site graph, divergence /
+ * gradient / Neumann-boundary data. */
+int tdgl_create(tdgl_ctx **out, const tdgl_mesh_desc *mesh, int device_id);
+void tdgl_destroy(tdgl_ctx *ctx);
+int tdgl_synchronize(tdgl_ctx *ctx);
+
+/* Upload the AMG hierarchy (levels[0] is the finest) and the dense pseudo-inverse
+ * [n_last, n_last] of the coarsest operator.  Replaces sp.linalg.factorized
+ * (operators.py:305-308). */
+int tdgl_poisson_set_hierarchy(tdgl_ctx *ctx, const tdgl_amg_level *levels, int32_t n_levels,
+                               const double *coarse_pinv);
+int tdgl_set_poisson_options(tdgl_ctx *ctx, const tdgl_poisson_options *opts);
+
+/* ------------------------------------------------------------------ inputs */
+/* MeshOperators.set_link_exponents (operators.py:310-383): A[n_edges, 2], dimensionless.
+ * Recomputes U_e = exp(-i A_e . d_e) and the covariant Laplacian / gradient values. */
+int tdgl_set_link_exponents(tdgl_ctx *ctx, const double *A);
+/* self.epsilon (solver.py:191-216, 645-648). */
+int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon);
+/* self.mu_boundary (solver.py:289, 325-345): indexed by position in boundary_edge_indices. */
+int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary);
+/* Initial / seed values of psi [n] complex and mu [n] (solver.py:284-288, 732-752). */
+int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu);
+/* SolverOptions fields + resets the controller state (tentative_dt = dt_init,
+ * d_psi_sq_vals = [], Runner.dt = dt_init; solver.py:316-320, runner.py:262). */
+int tdgl_set_controller(tdgl_ctx *ctx, const tdgl_controller *c);
+/* Probe sites (device.probe_point_indices, solver.py:142, 691-694); n_probe may be 0. */
+int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_probe);
+
+/* ------------------------------------------------------------------ the time loop */
+/* Start a Runner stage (runner.py:294-297, 315-318): time = 0, stage step = 0.  Runner.dt
+ * and the controller state are deliberately NOT reset. */
+int tdgl_begin_stage(tdgl_ctx *ctx);
+
+/* Runs TDGLSolver.update (solver.py:580-714) inside Runner._run_stage's loop
+ * (runner.py:379-433) for up to max_steps iterations, stopping after the iteration in which
+ * time >= end_time holds (the reference tests this AFTER stepping and BEFORE advancing
+ * time, so one step past end_time is taken).
+ *   out_dt[k]            dt used by iteration k                          (max_steps)
+ *   out_mu_probe         mu at the probe sites        [max_steps, n_probe] (may be NULL)
+ *   out_theta_probe      arg(psi) at the probe sites  [max_steps, n_probe] (may be NULL)
+ *   out_pcg_iters[k]     Poisson iterations used                          (may be NULL)
+ *   steps_done           iterations executed
+ *   reached_end          1 if the loop ended because time >= end_time
+ * Returns TDGL_ERR_PSI_RETRIES with the reference's message when the psi update fails. */
+int tdgl_run(tdgl_ctx *ctx, int64_t max_steps, double end_time, double *out_dt,
+             double *out_mu_probe, double *out_theta_probe, int32_t *out_pcg_iters,
+             int64_t *steps_done, int32_t *reached_end);
+
+/* Loop state: stage step index i, Runner.time, Runner.dt (state["dt"] of the next
+ * iteration), tentative_dt of the controller. */
+int tdgl_get_loop_state(tdgl_ctx *ctx, int64_t *step, double *time, double *runner_dt,
+                        double *tentative_dt);
+
+/* Overwrite the loop state (used by the host-side TDGLSolver.update() compatibility shim,
+ * whose caller owns step/time like the reference's Runner does, runner.py:381-384). */
+int tdgl_set_loop_state(tdgl_ctx *ctx, int64_t step, double time, double runner_dt);
+
+/* Current fields in reference ordering; any pointer may be NULL.  supercurrent and
+ * normal_current are [n_edges] (operators.py:385-394, solver.py:519). */
+int tdgl_get_state(tdgl_ctx *ctx, double *psi, double *mu, double *supercurrent,
+                   double *normal_current);
+
+/* ------------------------------------------------------------------ single operators
+ * (parity-test entry points; each mirrors one reference call, host buffers in/out) */
+/* psi_laplacian @ psi (operators.py:120-185 via :333-339). */
+int tdgl_apply_psi_laplacian(tdgl_ctx *ctx, const double *psi, double *out);
+/* MeshOperators.get_supercurrent (operators.py:385-394). */
+int tdgl_supercurrent(tdgl_ctx *ctx, const double *psi, double *out);
+/* TDGLSolver.solve_for_psi_squared (solver.py:383-439); *ok = 0 where the reference
+ * returns None.  Uses the context's epsilon, u, gamma and link variables. */
+int tdgl_psi_update(tdgl_ctx *ctx, const double *psi, const double *mu, double dt,
+                    double *psi_out, double *abs_sq_out, int32_t *ok);
+/* The right-hand side of the mu equation, divergence @ J_s - mu_boundary_laplacian @
+ * mu_boundary (solver.py:508-510), for a given psi. */
+int tdgl_poisson_rhs(tdgl_ctx *ctx, const double *psi, double *rhs);
+/* mu_laplacian_lu(rhs) (solver.py:516) up to the additive constant: returns the
+ * zero-mean solution.  mu_inout holds the initial guess on entry. */
+int tdgl_poisson_solve(tdgl_ctx *ctx, const double *rhs, double *mu_inout, int32_t *iters,
+                       double *relres);
+/* -(mu_gradient @ mu) (solver.py:519, operators.py:287). */
+int tdgl_normal_current(tdgl_ctx *ctx, const double *mu, double *out);
+/* One application of the AMG V-cycle preconditioner z = M^-1 r on level-0 vectors given in
+ * REFERENCE site order (for cross-checks against the host restatement of the cycle). */
+int tdgl_vcycle(tdgl_ctx *ctx, const double *r, double *z);
+
+/* ------------------------------------------------------------------ measurement */
+/* Average duration (ms) of `reps` back-to-back launches of one kernel on the context's
+ * stream, timed with HIP events.  kernel: 0 = psi-Laplacian SpMV (K1), 1 = fused
+ * psi-Laplacian + rhs, 2 = pointwise psi update, 3 = edge currents, 4 = level-0 Poisson
+ * SpMV, 5 = level-0 V-cycle, 6 = copy (device memcpy ceiling, bytes = 16 * n_sites r+w). */
+int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms);
+/* Enable/disable HIP-event timing of the fused psi-Laplacian kernel inside tdgl_run, and
+ * read back the accumulated launches / milliseconds. */
+int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on);
+int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDGL_HIP_H */

@@ -1,0 +1,693 @@
+// libtdgl_hip: MI355X-native TDGL time-stepping core behind a C ABI (include/tdgl_hip.h).
+// Single translation unit: kernels (kernels.inc), Poisson solver (poisson.inc), the
+// per-step driver (run.inc).
+
+#include "tdgl_internal.h"
+
+static thread_local std::string g_last_error;
+
+#define TDGL_FAIL(ctx, code, ...)                                   \
+    do {                                                            \
+        char _buf[512];                                             \
+        snprintf(_buf, sizeof(_buf), __VA_ARGS__);                  \
+        if (ctx) (ctx)->err = _buf;                                 \
+        g_last_error = _buf;                                        \
+        return (code);                                              \
+    } while (0)
+
+#define HIP_TRY(ctx, expr)                                                               \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            TDGL_FAIL(ctx, TDGL_ERR_HIP, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), \
+                      __FILE__, __LINE__, #expr);                                        \
+    } while (0)
+
+#define TDGL_TRY(expr)                 \
+    do {                               \
+        int _s = (expr);               \
+        if (_s != TDGL_OK) return _s;  \
+    } while (0)
+
+#include "kernels.inc"
+
+using namespace tdgl;
+
+static inline int grid_for(int64_t n, int block = BLOCK) { return (int)((n + block - 1) / block); }
+
+// number of workgroups for a SELL kernel: 4 slices per group, rounded up to a multiple of
+// the XCD count so that xcd_tile() is a bijection onto [0, per_xcd * 8)
+static inline void sell_grid(int n_slices, int *per_xcd, int *grid) {
+    const int tiles = (n_slices + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+    *per_xcd = (tiles + XCDS - 1) / XCDS;
+    if (*per_xcd < 1) *per_xcd = 1;
+    *grid = *per_xcd * XCDS;
+}
+
+// ---------------------------------------------------------------------------------------
+// SELL construction from CSR (host)
+static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
+                              const int32_t *indices, SellPattern &pat,
+                              std::vector<int64_t> *slot_of_nnz) {
+    pat.n_rows = n_rows;
+    pat.n_pad = round_up(std::max<int64_t>(n_rows, 1), WAVE);
+    pat.n_slices = (int32_t)(pat.n_pad / WAVE);
+    std::vector<int32_t> off(pat.n_slices + 1, 0);
+    for (int s = 0; s < pat.n_slices; ++s) {
+        int w = 0;
+        for (int64_t r = (int64_t)s * WAVE; r < std::min<int64_t>(n_rows, (int64_t)(s + 1) * WAVE); ++r)
+            w = std::max(w, indptr[r + 1] - indptr[r]);
+        off[s + 1] = off[s] + w;
+    }
+    pat.n_slots = (int64_t)off[pat.n_slices] * WAVE;
+    std::vector<int32_t> cols(pat.n_slots);
+    if (slot_of_nnz) slot_of_nnz->assign(indptr[n_rows], -1);
+    for (int s = 0; s < pat.n_slices; ++s) {
+        const int w = off[s + 1] - off[s];
+        for (int lane = 0; lane < WAVE; ++lane) {
+            const int64_t r = (int64_t)s * WAVE + lane;
+            const int deg = (r < n_rows) ? indptr[r + 1] - indptr[r] : 0;
+            for (int k = 0; k < w; ++k) {
+                const int64_t slot = ((int64_t)off[s] + k) * WAVE + lane;
+                if (k < deg) {
+                    cols[slot] = indices[indptr[r] + k];
+                    if (slot_of_nnz) (*slot_of_nnz)[indptr[r] + k] = slot;
+                } else {
+                    cols[slot] = (int32_t)r;  // padding: own row, value 0
+                }
+            }
+        }
+    }
+    HIP_TRY(ctx, pat.slice_off.upload(off));
+    HIP_TRY(ctx, pat.cols.upload(cols));
+    return TDGL_OK;
+}
+
+static int build_sell_f64(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
+                          const int32_t *indices, const double *data, SellF64 &A) {
+    std::vector<int64_t> slot;
+    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr, indices, A.pat, &slot));
+    std::vector<double> vals(A.pat.n_slots, 0.0);
+    for (int64_t k = 0; k < indptr[n_rows]; ++k) vals[slot[k]] = data[k];
+    HIP_TRY(ctx, A.vals.upload(vals));
+    return TDGL_OK;
+}
+
+static int upload_csr(tdgl_ctx *ctx, int64_t n_rows, int64_t n_cols, const int32_t *indptr,
+                      const int32_t *indices, const double *data, Csr &M) {
+    M.n_rows = n_rows;
+    M.n_cols = n_cols;
+    M.nnz = indptr[n_rows];
+    HIP_TRY(ctx, M.indptr.upload(std::vector<int32_t>(indptr, indptr + n_rows + 1)));
+    HIP_TRY(ctx, M.indices.upload(std::vector<int32_t>(indices, indices + M.nnz)));
+    HIP_TRY(ctx, M.data.upload(std::vector<double>(data, data + M.nnz)));
+    return TDGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int tdgl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *tdgl_version(void) { return "tdgl_hip 0.1.0 (gfx950)"; }
+
+extern "C" const char *tdgl_last_error(const tdgl_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto *lv : ctx->levels) delete lv;
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->h_probe_out) (void)hipHostFree(ctx->h_probe_out);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto &pr : ctx->prof_pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    hipStream_t s = ctx->stream;
+    delete ctx;  // frees the DevBufs
+    if (s) (void)hipStreamDestroy(s);
+}
+
+extern "C" int tdgl_synchronize(tdgl_ctx *ctx) {
+    if (!ctx) return TDGL_ERR_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TDGL_OK;
+}
+
+static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
+    const int64_t n = d->n_sites, m = d->n_edges, nb = d->n_boundary_edges;
+    ctx->n = n;
+    ctx->m = m;
+    ctx->nb = nb;
+    ctx->n_pad = round_up(n, WAVE);
+    ctx->m_pad = round_up(std::max<int64_t>(m, 1), WAVE);
+    ctx->u = d->u;
+    ctx->gamma = d->gamma;
+    ctx->fix_psi = d->fix_psi != 0;
+
+    // ---- site permutation ----------------------------------------------------------
+    ctx->perm.resize(n);
+    ctx->iperm.assign(n, -1);
+    for (int64_t i = 0; i < n; ++i) ctx->perm[i] = d->site_perm ? d->site_perm[i] : (int32_t)i;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t r = ctx->perm[i];
+        if (r < 0 || r >= n || ctx->iperm[r] != -1)
+            TDGL_FAIL(ctx, TDGL_ERR_ARG, "site_perm is not a permutation of 0..n_sites-1");
+        ctx->iperm[r] = (int32_t)i;
+    }
+
+    // ---- edges in internal numbering, sorted for gather locality ---------------------
+    std::vector<int32_t> p0(m), p1(m);
+    for (int64_t e = 0; e < m; ++e) {
+        const int32_t i = d->edges[2 * e], j = d->edges[2 * e + 1];
+        if (i < 0 || i >= n || j < 0 || j >= n || i == j)
+            TDGL_FAIL(ctx, TDGL_ERR_ARG, "edge %lld has invalid sites (%d, %d)", (long long)e, i, j);
+        p0[e] = ctx->iperm[i];
+        p1[e] = ctx->iperm[j];
+    }
+    ctx->edge_perm.resize(m);
+    std::iota(ctx->edge_perm.begin(), ctx->edge_perm.end(), 0);
+    std::sort(ctx->edge_perm.begin(), ctx->edge_perm.end(), [&](int32_t a, int32_t b) {
+        const int32_t alo = std::min(p0[a], p1[a]), ahi = std::max(p0[a], p1[a]);
+        const int32_t blo = std::min(p0[b], p1[b]), bhi = std::max(p0[b], p1[b]);
+        return alo != blo ? alo < blo : (ahi != bhi ? ahi < bhi : a < b);
+    });
+    ctx->edge_iperm.resize(m);
+    for (int64_t k = 0; k < m; ++k) ctx->edge_iperm[ctx->edge_perm[k]] = (int32_t)k;
+
+    std::vector<int32_t> e0(ctx->m_pad, 0), e1(ctx->m_pad, 0);
+    std::vector<double> inv_len(ctx->m_pad, 0.0), dx(ctx->m_pad, 0.0), dy(ctx->m_pad, 0.0), w(m);
+    for (int64_t k = 0; k < m; ++k) {
+        const int32_t e = ctx->edge_perm[k];
+        e0[k] = p0[e];
+        e1[k] = p1[e];
+        if (!(d->edge_lengths[e] > 0.0) || !(d->dual_edge_lengths[e] >= 0.0))
+            TDGL_FAIL(ctx, TDGL_ERR_ARG, "edge %d has non-positive length or negative dual length", e);
+        inv_len[k] = 1 / d->edge_lengths[e];                       // operators.py:271
+        w[k] = d->dual_edge_lengths[e] / d->edge_lengths[e];       // operators.py:272
+        dx[k] = d->directions[2 * e];
+        dy[k] = d->directions[2 * e + 1];
+    }
+
+    // ---- site graph (CSR, neighbours sorted) -> SELL pattern ------------------------
+    std::vector<int32_t> deg(n + 1, 0);
+    for (int64_t k = 0; k < m; ++k) {
+        deg[e0[k] + 1]++;
+        deg[e1[k] + 1]++;
+    }
+    std::vector<int32_t> indptr(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) indptr[i + 1] = indptr[i] + deg[i + 1];
+    std::vector<int32_t> nbr(2 * m), code(2 * m), fill(indptr.begin(), indptr.end() - 1);
+    for (int64_t k = 0; k < m; ++k) {  // edges sorted by min site -> rows fill in order
+        nbr[fill[e0[k]]] = e1[k];
+        code[fill[e0[k]]++] = (int32_t)(k << 1);        // row = tail: U_e
+        nbr[fill[e1[k]]] = e0[k];
+        code[fill[e1[k]]++] = (int32_t)(k << 1) | 1;    // row = head: conj(U_e)
+    }
+    for (int64_t i = 0; i < n; ++i) {  // sort each row by neighbour index
+        const int b = indptr[i], e = indptr[i + 1];
+        std::vector<std::pair<int32_t, int32_t>> row(e - b);
+        for (int k = b; k < e; ++k) row[k - b] = {nbr[k], code[k]};
+        std::sort(row.begin(), row.end());
+        for (int k = b; k < e; ++k) {
+            nbr[k] = row[k - b].first;
+            code[k] = row[k - b].second;
+        }
+    }
+    std::vector<int64_t> slot;
+    TDGL_TRY(build_sell_pattern(ctx, n, indptr.data(), nbr.data(), ctx->lap_pat, &slot));
+    const int64_t n_slots = ctx->lap_pat.n_slots;
+    std::vector<int32_t> slot_edge(n_slots, -1);
+    std::vector<double> slot_w(n_slots, 0.0), diag(ctx->n_pad, 0.0), area(ctx->n_pad, 0.0);
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = d->areas[ctx->perm[i]];
+        if (!(a > 0.0)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "site %d has non-positive area", ctx->perm[i]);
+        area[i] = a;
+        double dsum = 0.0;
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const double wk = w[code[k] >> 1];
+            slot_edge[slot[k]] = code[k];
+            slot_w[slot[k]] = wk / a;
+            dsum += -wk / a;  // operators.py:166-167
+        }
+        diag[i] = dsum;
+    }
+    std::vector<uint8_t> fixed(ctx->n_pad, 0);
+    if (d->fix_psi)
+        for (int64_t k = 0; k < d->n_fixed; ++k) {
+            const int32_t s = d->fixed_sites[k];
+            if (s < 0 || s >= n) TDGL_FAIL(ctx, TDGL_ERR_ARG, "fixed site %d out of range", s);
+            fixed[ctx->iperm[s]] = 1;
+        }
+
+    HIP_TRY(ctx, ctx->lap_slot_edge.upload(slot_edge));
+    HIP_TRY(ctx, ctx->lap_slot_w.upload(slot_w));
+    HIP_TRY(ctx, ctx->lap_vals.alloc(n_slots));
+    HIP_TRY(ctx, ctx->lap_diag.upload(diag));
+    HIP_TRY(ctx, ctx->fixed_mask.upload(fixed));
+    HIP_TRY(ctx, ctx->area.upload(area));
+    HIP_TRY(ctx, ctx->e0.upload(e0));
+    HIP_TRY(ctx, ctx->e1.upload(e1));
+    HIP_TRY(ctx, ctx->e_inv_len.upload(inv_len));
+    HIP_TRY(ctx, ctx->e_dirx.upload(dx));
+    HIP_TRY(ctx, ctx->e_diry.upload(dy));
+    HIP_TRY(ctx, ctx->e_U.alloc(ctx->m_pad));
+    HIP_TRY(ctx, ctx->e_A.alloc(2 * ctx->m_pad));
+
+    // ---- Neumann boundary term (operators.py:188-230) -------------------------------
+    std::vector<int32_t> s0(std::max<int64_t>(nb, 1), 0), s1(std::max<int64_t>(nb, 1), 0);
+    std::vector<double> c0(std::max<int64_t>(nb, 1), 0.0), c1(std::max<int64_t>(nb, 1), 0.0);
+    for (int64_t k = 0; k < nb; ++k) {
+        const int32_t e = d->boundary_edge_indices[k];
+        if (e < 0 || e >= m) TDGL_FAIL(ctx, TDGL_ERR_ARG, "boundary edge %d out of range", e);
+        const int32_t i = d->edges[2 * e], j = d->edges[2 * e + 1];
+        s0[k] = ctx->iperm[i];
+        s1[k] = ctx->iperm[j];
+        c0[k] = d->edge_lengths[e] / (2 * d->areas[i]);
+        c1[k] = d->edge_lengths[e] / (2 * d->areas[j]);
+    }
+    HIP_TRY(ctx, ctx->b_s0.upload(s0));
+    HIP_TRY(ctx, ctx->b_s1.upload(s1));
+    HIP_TRY(ctx, ctx->b_c0.upload(c0));
+    HIP_TRY(ctx, ctx->b_c1.upload(c1));
+    HIP_TRY(ctx, ctx->b_mu.alloc(std::max<int64_t>(nb, 1)));
+    HIP_TRY(ctx, ctx->cvec.alloc(ctx->n_pad));
+
+    // ---- state ------------------------------------------------------------------------
+    HIP_TRY(ctx, ctx->psi[0].alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->psi[1].alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->lap[0].alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->lap[1].alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->mu.alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->eps.alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->bvec.alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->js.alloc(ctx->m_pad));
+    HIP_TRY(ctx, ctx->jn.alloc(ctx->m_pad));
+    HIP_TRY(ctx, ctx->d_status.alloc(1));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(StepStatus)));
+    memset(ctx->h_status, 0, sizeof(StepStatus));
+    HIP_TRY(ctx, ctx->scal.alloc(S_COUNT));
+    HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
+    HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_create(tdgl_ctx **out, const tdgl_mesh_desc *d, int device_id) {
+    if (!out || !d) TDGL_FAIL((tdgl_ctx *)nullptr, TDGL_ERR_ARG, "tdgl_create: null argument");
+    *out = nullptr;
+    if (d->n_sites <= 0 || d->n_edges <= 0 || d->n_boundary_edges < 0 || !d->edges || !d->areas ||
+        !d->edge_lengths || !d->dual_edge_lengths || !d->directions ||
+        (d->n_boundary_edges > 0 && !d->boundary_edge_indices) || (d->n_fixed > 0 && !d->fixed_sites))
+        TDGL_FAIL((tdgl_ctx *)nullptr, TDGL_ERR_ARG, "tdgl_create: incomplete mesh description");
+    if (d->n_sites >= (1ll << 30) || d->n_edges >= (1ll << 30))
+        TDGL_FAIL((tdgl_ctx *)nullptr, TDGL_ERR_ARG, "tdgl_create: mesh too large for int32 indices");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        TDGL_FAIL((tdgl_ctx *)nullptr, TDGL_ERR_HIP,
+                  "tdgl_create: no HIP device available (%s); this library has no CPU fallback",
+                  hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev)
+        TDGL_FAIL((tdgl_ctx *)nullptr, TDGL_ERR_ARG, "tdgl_create: device %d not in [0, %d)", device_id, ndev);
+    tdgl_ctx *ctx = new tdgl_ctx();
+    ctx->device = device_id;
+    int st = TDGL_OK;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        g_last_error = "tdgl_create: cannot select device / create stream";
+        st = TDGL_ERR_HIP;
+    } else {
+        st = create_impl(ctx, d);
+    }
+    if (st != TDGL_OK) {
+        g_last_error = ctx->err.empty() ? g_last_error : ctx->err;
+        tdgl_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return TDGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host <-> device with the site / edge permutation applied
+template <class T>
+static int upload_sites(tdgl_ctx *ctx, const T *ref, DevBuf<T> &dst) {
+    std::vector<T> tmp(ctx->n_pad, T{});
+    for (int64_t i = 0; i < ctx->n; ++i) tmp[i] = ref[ctx->perm[i]];
+    HIP_TRY(ctx, hipMemcpyAsync(dst.p, tmp.data(), ctx->n_pad * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TDGL_OK;
+}
+
+template <class T>
+static int download_sites(tdgl_ctx *ctx, const T *src, T *ref) {
+    std::vector<T> tmp(ctx->n);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), src, ctx->n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < ctx->n; ++i) ref[ctx->perm[i]] = tmp[i];
+    return TDGL_OK;
+}
+
+static int download_edges(tdgl_ctx *ctx, const double *src, double *ref) {
+    std::vector<double> tmp(ctx->m);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), src, ctx->m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t k = 0; k < ctx->m; ++k) ref[ctx->edge_perm[k]] = tmp[k];
+    return TDGL_OK;
+}
+
+#define CTX_GUARD(ctx)                              \
+    do {                                            \
+        if (!(ctx)) return TDGL_ERR_ARG;            \
+        HIP_TRY(ctx, hipSetDevice((ctx)->device));  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, double2 *lap) {
+    int per_xcd, grid;
+    sell_grid(ctx->lap_pat.n_slices, &per_xcd, &grid);
+    if (rhs)
+        hipLaunchKernelGGL(k_psi_laplacian<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
+                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
+                           ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
+                           ctx->cvec.p, ctx->bvec.p);
+    else
+        hipLaunchKernelGGL(k_psi_laplacian<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
+                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
+                           ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
+                           ctx->cvec.p, ctx->bvec.p);
+}
+
+static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
+                              double dt, double2 *psi_new, double *abs_sq) {
+    const int grid = std::min<int64_t>(grid_for(ctx->n), 256 * 16);
+    hipLaunchKernelGGL(k_psi_update, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->n, psi, mu,
+                       ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p);
+}
+
+static void launch_edge_currents(tdgl_ctx *ctx, const double2 *psi, const double *mu, double *js,
+                                 double *jn) {
+    const int grid = grid_for(ctx->m);
+    if (js && jn)
+        hipLaunchKernelGGL((k_edge_currents<true, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
+    else if (js)
+        hipLaunchKernelGGL((k_edge_currents<true, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
+    else if (jn)
+        hipLaunchKernelGGL((k_edge_currents<false, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
+}
+
+#include "poisson.inc"
+#include "run.inc"
+
+// ---------------------------------------------------------------------------------------
+extern "C" int tdgl_set_link_exponents(tdgl_ctx *ctx, const double *A) {
+    CTX_GUARD(ctx);
+    if (!A) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_link_exponents: null A");
+    std::vector<double> tmp(2 * ctx->m_pad, 0.0);
+    for (int64_t k = 0; k < ctx->m; ++k) {
+        const int32_t e = ctx->edge_perm[k];
+        tmp[2 * k] = A[2 * e];
+        tmp[2 * k + 1] = A[2 * e + 1];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->e_A.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_link_variables, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m,
+                       ctx->e_A.p, ctx->e_dirx.p, ctx->e_diry.p, ctx->e_U.p);
+    hipLaunchKernelGGL(k_fill_laplacian, dim3(grid_for(ctx->lap_pat.n_slots)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->lap_pat.n_slots, ctx->lap_slot_edge.p, ctx->lap_slot_w.p, ctx->e_U.p, ctx->lap_vals.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_links = true;
+    ctx->lap_valid = false;
+    ctx->currents_valid = false;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon) {
+    CTX_GUARD(ctx);
+    if (!epsilon) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_epsilon: null epsilon");
+    TDGL_TRY(upload_sites(ctx, epsilon, ctx->eps));
+    ctx->have_eps = true;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
+    CTX_GUARD(ctx);
+    if (ctx->nb > 0 && !mu_boundary) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_mu_boundary: null array");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->cvec.p, 0, ctx->n_pad * sizeof(double), ctx->stream));
+    if (ctx->nb > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->b_mu.p, mu_boundary, ctx->nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_boundary_term, dim3(grid_for(ctx->nb)), dim3(BLOCK), 0, ctx->stream, ctx->nb,
+                           ctx->b_s0.p, ctx->b_s1.p, ctx->b_c0.p, ctx->b_c1.p, ctx->b_mu.p, ctx->cvec.p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu) {
+    CTX_GUARD(ctx);
+    if (!psi || !mu) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_state: null array");
+    TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), ctx->psi[ctx->cur]));
+    TDGL_TRY(upload_sites(ctx, mu, ctx->mu));
+    ctx->have_state = true;
+    ctx->lap_valid = false;
+    ctx->currents_valid = false;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_controller(tdgl_ctx *ctx, const tdgl_controller *c) {
+    if (!ctx || !c) return TDGL_ERR_ARG;
+    if (c->dt_init > c->dt_max) TDGL_FAIL(ctx, TDGL_ERR_ARG, "dt_init must be less than or equal to dt_max.");
+    if (!(c->adaptive_time_step_multiplier > 0 && c->adaptive_time_step_multiplier < 1))
+        TDGL_FAIL(ctx, TDGL_ERR_ARG, "adaptive_time_step_multiplier must be in (0, 1) (got %g).",
+                  c->adaptive_time_step_multiplier);
+    ctx->ctl = *c;
+    ctx->tentative_dt = c->dt_init;                       // solver.py:319
+    ctx->dt_cap = c->adaptive ? c->dt_max : c->dt_init;   // solver.py:320
+    ctx->d_psi_sq_vals.clear();                           // solver.py:318
+    ctx->runner_dt = c->dt_init;                          // runner.py:262
+    ctx->time = 0.0;
+    ctx->stage_step = 0;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_probe) {
+    CTX_GUARD(ctx);
+    if (n_probe < 0 || (n_probe > 0 && !sites)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_probes: bad arguments");
+    ctx->probes.clear();
+    for (int k = 0; k < n_probe; ++k) {
+        if (sites[k] < 0 || sites[k] >= ctx->n) TDGL_FAIL(ctx, TDGL_ERR_ARG, "probe site %d out of range", sites[k]);
+        ctx->probes.push_back(ctx->iperm[sites[k]]);
+    }
+    if (ctx->h_probe_out) {
+        (void)hipHostFree(ctx->h_probe_out);
+        ctx->h_probe_out = nullptr;
+    }
+    if (n_probe > 0) {
+        HIP_TRY(ctx, ctx->d_probes.upload(ctx->probes));
+        HIP_TRY(ctx, ctx->d_probe_out.alloc(2 * n_probe));
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_probe_out), 2 * n_probe * sizeof(double)));
+    }
+    return TDGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+static int ensure_currents(tdgl_ctx *ctx) {
+    if (ctx->currents_valid) return TDGL_OK;
+    if (!ctx->have_links) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "link exponents not set");
+    launch_edge_currents(ctx, ctx->psi[ctx->cur].p, ctx->mu.p, ctx->js.p, ctx->jn.p);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->currents_valid = true;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_get_state(tdgl_ctx *ctx, double *psi, double *mu, double *supercurrent,
+                              double *normal_current) {
+    CTX_GUARD(ctx);
+    if (!ctx->have_state) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "tdgl_get_state: no state set");
+    if (psi) TDGL_TRY(download_sites(ctx, ctx->psi[ctx->cur].p, reinterpret_cast<double2 *>(psi)));
+    if (mu) TDGL_TRY(download_sites(ctx, ctx->mu.p, mu));
+    if (supercurrent || normal_current) {
+        TDGL_TRY(ensure_currents(ctx));
+        if (supercurrent) TDGL_TRY(download_edges(ctx, ctx->js.p, supercurrent));
+        if (normal_current) TDGL_TRY(download_edges(ctx, ctx->jn.p, normal_current));
+    }
+    return TDGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// single-operator entry points (parity tests)
+struct Scratch {
+    DevBuf<double2> c0, c1;
+    DevBuf<double> r0, r1;
+};
+
+extern "C" int tdgl_apply_psi_laplacian(tdgl_ctx *ctx, const double *psi, double *out) {
+    CTX_GUARD(ctx);
+    if (!psi || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (!ctx->have_links) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "link exponents not set");
+    Scratch s;
+    HIP_TRY(ctx, s.c0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.c1.alloc(ctx->n_pad));
+    TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), s.c0));
+    launch_psi_laplacian(ctx, false, s.c0.p, s.c1.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return download_sites(ctx, s.c1.p, reinterpret_cast<double2 *>(out));
+}
+
+extern "C" int tdgl_supercurrent(tdgl_ctx *ctx, const double *psi, double *out) {
+    CTX_GUARD(ctx);
+    if (!psi || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (!ctx->have_links) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "link exponents not set");
+    Scratch s;
+    HIP_TRY(ctx, s.c0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.r0.alloc(ctx->m_pad));
+    TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), s.c0));
+    launch_edge_currents(ctx, s.c0.p, nullptr, s.r0.p, nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+    return download_edges(ctx, s.r0.p, out);
+}
+
+extern "C" int tdgl_normal_current(tdgl_ctx *ctx, const double *mu, double *out) {
+    CTX_GUARD(ctx);
+    if (!mu || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    Scratch s;
+    HIP_TRY(ctx, s.r0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.r1.alloc(ctx->m_pad));
+    TDGL_TRY(upload_sites(ctx, mu, s.r0));
+    launch_edge_currents(ctx, nullptr, s.r0.p, nullptr, s.r1.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return download_edges(ctx, s.r1.p, out);
+}
+
+extern "C" int tdgl_psi_update(tdgl_ctx *ctx, const double *psi, const double *mu, double dt,
+                               double *psi_out, double *abs_sq_out, int32_t *ok) {
+    CTX_GUARD(ctx);
+    if (!psi || !mu || !psi_out || !ok) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (!ctx->have_links || !ctx->have_eps) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "link exponents / epsilon not set");
+    Scratch s;
+    DevBuf<double2> lap, pnew;
+    HIP_TRY(ctx, s.c0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, lap.alloc(ctx->n_pad));
+    HIP_TRY(ctx, pnew.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.r0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.r1.alloc(ctx->n_pad));
+    TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), s.c0));
+    TDGL_TRY(upload_sites(ctx, mu, s.r0));
+    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status.p);
+    launch_psi_laplacian(ctx, false, s.c0.p, lap.p);
+    launch_psi_update(ctx, s.c0.p, s.r0.p, lap.p, dt, pnew.p, s.r1.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status.p, sizeof(StepStatus), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *ok = ctx->h_status->fail_flag ? 0 : 1;
+    TDGL_TRY(download_sites(ctx, pnew.p, reinterpret_cast<double2 *>(psi_out)));
+    if (abs_sq_out) TDGL_TRY(download_sites(ctx, s.r1.p, abs_sq_out));
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_poisson_rhs(tdgl_ctx *ctx, const double *psi, double *rhs) {
+    CTX_GUARD(ctx);
+    if (!psi || !rhs) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (!ctx->have_links) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "link exponents not set");
+    Scratch s;
+    HIP_TRY(ctx, s.c0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.c1.alloc(ctx->n_pad));
+    TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), s.c0));
+    launch_psi_laplacian(ctx, true, s.c0.p, s.c1.p);  // writes ctx->bvec = -a * rhs
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<double> b(ctx->n);
+    HIP_TRY(ctx, hipMemcpyAsync(b.data(), ctx->bvec.p, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> area(ctx->n);
+    HIP_TRY(ctx, hipMemcpyAsync(area.data(), ctx->area.p, ctx->n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < ctx->n; ++i) rhs[ctx->perm[i]] = -b[i] / area[i];
+    return TDGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+extern "C" int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on) {
+    if (!ctx) return TDGL_ERR_ARG;
+    ctx->profile = on != 0;
+    ctx->prof_launches = 0;
+    ctx->prof_ms = 0.0;
+    return TDGL_OK;
+}
+
+static int profile_drain(tdgl_ctx *ctx) {
+    for (auto &pr : ctx->prof_pending) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->prof_ms += ms;
+        ctx->prof_launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ctx->prof_pending.clear();
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total_ms) {
+    CTX_GUARD(ctx);
+    TDGL_TRY(profile_drain(ctx));
+    if (launches) *launches = ctx->prof_launches;
+    if (total_ms) *total_ms = ctx->prof_ms;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms) {
+    CTX_GUARD(ctx);
+    if (!avg_ms || reps <= 0) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_time_kernel: bad arguments");
+    if (!ctx->have_links || !ctx->have_state || !ctx->have_eps)
+        TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "tdgl_time_kernel: set link exponents, epsilon and state first");
+    if ((kernel == 4 || kernel == 5) && ctx->levels.empty())
+        TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "tdgl_time_kernel: no AMG hierarchy");
+    DevBuf<double2> tmp_c;
+    DevBuf<double> tmp_r, tmp_r2;
+    HIP_TRY(ctx, tmp_c.alloc(ctx->n_pad));
+    HIP_TRY(ctx, tmp_r.alloc(std::max(ctx->n_pad, ctx->m_pad)));
+    HIP_TRY(ctx, tmp_r2.alloc(std::max(ctx->n_pad, ctx->m_pad)));
+    const double2 *psi = ctx->psi[ctx->cur].p;
+    auto once = [&]() -> int {
+        switch (kernel) {
+            case 0: launch_psi_laplacian(ctx, false, psi, tmp_c.p); break;
+            case 1: launch_psi_laplacian(ctx, true, psi, tmp_c.p); break;
+            case 2: launch_psi_update(ctx, psi, ctx->mu.p, ctx->lap[ctx->cur].p, 1e-4, tmp_c.p, nullptr); break;
+            case 3: launch_edge_currents(ctx, psi, ctx->mu.p, tmp_r.p, tmp_r2.p); break;
+            case 4: poisson_spmv_level0(ctx, ctx->mu.p, tmp_r.p); break;
+            case 5: vcycle(ctx, ctx->bvec.p, /*result*/ nullptr); break;
+            case 6:
+                hipLaunchKernelGGL(k_copy_d2, dim3(grid_for(ctx->n_pad)), dim3(BLOCK), 0, ctx->stream,
+                                   ctx->n_pad, psi, tmp_c.p);
+                break;
+            default: return TDGL_ERR_ARG;
+        }
+        return TDGL_OK;
+    };
+    for (int i = 0; i < 3; ++i)
+        if (once() != TDGL_OK) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_time_kernel: unknown kernel %d", kernel);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < reps; ++i) (void)once();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_TRY(ctx, hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)ms / reps;
+    // the step status may have been touched by the psi-update kernel; reset it
+    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status.p);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TDGL_OK;
+}

@@ -1,0 +1,179 @@
+// Internal declarations of libtdgl_hip (gfx950 only).  See include/tdgl_hip.h for the ABI
+// and DESIGN.md for the data layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "tdgl_hip.h"
+
+namespace tdgl {
+
+constexpr int WAVE = 64;        // CDNA wavefront
+constexpr int BLOCK = 256;      // 4 waves per workgroup
+constexpr int XCDS = 8;         // MI355X accelerator complex dies (one L2 each)
+constexpr int REDUCE_BLOCK = 1024;
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- device buffers
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count, bool zero = true) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            n = 0;
+            return e;
+        }
+        if (zero) e = hipMemset(p, 0, count * sizeof(T));
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size(), false);
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// SELL-C-sigma with C = 64 (one slice per wavefront, sigma = 1: row order is kept, the
+// site permutation already groups rows of equal degree).  Entry k of row r of slice s is
+// stored at (slice_off[s] + k) * 64 + (r % 64): a wavefront's loads are 64 consecutive
+// elements.  Padding entries point at the row itself with value 0.
+struct SellPattern {
+    int64_t n_rows = 0, n_pad = 0;
+    int32_t n_slices = 0;
+    int64_t n_slots = 0;  // slice_off[n_slices] * 64
+    DevBuf<int32_t> slice_off;
+    DevBuf<int32_t> cols;
+};
+
+struct SellF64 {
+    SellPattern pat;
+    DevBuf<double> vals;
+};
+
+struct Csr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    DevBuf<int32_t> indptr, indices;
+    DevBuf<double> data;
+};
+
+struct AmgLevel {
+    int64_t n = 0, n_pad = 0, n_coarse = 0;
+    double rho = 2.0, omega = 2.0 / 3.0;
+    SellF64 A;
+    DevBuf<double> dinv;
+    Csr P, R;
+    DevBuf<double> xa, xb, b, r;  // level vectors (level 0 borrows b/x from PCG)
+};
+
+// scalars of the PCG recurrence, resident on the device
+enum Scal { S_RZ = 0, S_PQ, S_RR, S_BB, S_ALPHA, S_BETA, S_SUM, S_COUNT = 8 };
+
+// what a step reports back to the host at its synchronisation point
+struct StepStatus {
+    int32_t fail_flag;          // psi update: discriminant < 0 or non-finite somewhere
+    int32_t pad;
+    unsigned long long dmax_bits;  // max | |psi'|^2 - |psi|^2 | as ordered uint64 bits
+    double scal[S_COUNT];
+};
+
+}  // namespace tdgl
+
+struct tdgl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    int64_t n = 0, m = 0, nb = 0, n_pad = 0, m_pad = 0;
+    double u = 5.79, gamma = 10.0;
+    bool fix_psi = true;
+
+    // permutations (host)
+    std::vector<int32_t> perm, iperm;            // internal -> reference site, and inverse
+    std::vector<int32_t> edge_perm, edge_iperm;  // internal -> reference edge, and inverse
+
+    // ---- psi operators -------------------------------------------------------------
+    tdgl::SellPattern lap_pat;            // off-diagonal pattern of the site graph
+    tdgl::DevBuf<double2> lap_vals;       // (w_e / a_i) * U_ij, per slot
+    tdgl::DevBuf<double> lap_slot_w;      // w_e / a_i per slot (static)
+    tdgl::DevBuf<int32_t> lap_slot_edge;  // (internal edge << 1) | conj flag, -1 = padding
+    tdgl::DevBuf<double> lap_diag;        // -sum_j w_ij / a_i
+    tdgl::DevBuf<uint8_t> fixed_mask;     // 1 = identity row (terminal site with fix_psi)
+    tdgl::DevBuf<double> area;            // a_i (0 on padding rows)
+    // per edge (internal order, reference orientation)
+    tdgl::DevBuf<int32_t> e0, e1;
+    tdgl::DevBuf<double> e_inv_len, e_dirx, e_diry;
+    tdgl::DevBuf<double2> e_U;
+    tdgl::DevBuf<double> e_A;             // staging for link exponents [2 * m_pad]
+    // boundary term: c = mu_boundary_laplacian @ mu_boundary
+    tdgl::DevBuf<int32_t> b_s0, b_s1;
+    tdgl::DevBuf<double> b_c0, b_c1, b_mu;
+    tdgl::DevBuf<double> cvec;
+
+    // ---- state ---------------------------------------------------------------------
+    tdgl::DevBuf<double2> psi[2];
+    int cur = 0;                          // psi[cur] is psi^n
+    tdgl::DevBuf<double2> lap[2];         // lap[cur] = L_psi psi^n (cached between steps)
+    bool lap_valid = false;
+    tdgl::DevBuf<double> mu, eps, bvec;
+    tdgl::DevBuf<double> js, jn;          // per edge, internal order
+    bool currents_valid = false;
+    bool have_links = false, have_state = false, have_eps = false;
+
+    // ---- Poisson ---------------------------------------------------------------------
+    std::vector<tdgl::AmgLevel *> levels;
+    tdgl::DevBuf<double> coarse_pinv;
+    int64_t n_coarsest = 0;
+    tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q, pcg_za, pcg_zb;
+    tdgl::DevBuf<double> partials;        // per-block partial sums
+    tdgl::DevBuf<double> scal;            // tdgl::Scal
+    tdgl_poisson_options popt{1e-10, 200, 1, 1, 1};
+    int32_t last_pcg_iters = 0;
+    double last_relres = 0.0;
+
+    // ---- step status / probes --------------------------------------------------------
+    tdgl::DevBuf<tdgl::StepStatus> d_status;
+    tdgl::StepStatus *h_status = nullptr;  // pinned
+    std::vector<int32_t> probes;           // internal site ids
+    tdgl::DevBuf<int32_t> d_probes;
+    tdgl::DevBuf<double> d_probe_out;      // [2 * n_probe]
+    double *h_probe_out = nullptr;         // pinned
+
+    // ---- controller / loop state (host; mirrors solver.py:316-320, runner.py:260-263) --
+    tdgl_controller ctl{1e-6, 1e-1, 1, 10, 10, 0.25};
+    double tentative_dt = 1e-6, dt_cap = 1e-1;
+    std::vector<double> d_psi_sq_vals;
+    double runner_dt = 1e-6, time = 0.0;
+    int64_t stage_step = 0;
+
+    // ---- measurement -------------------------------------------------------------------
+    bool profile = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+};

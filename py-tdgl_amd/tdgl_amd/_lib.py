@@ -1,0 +1,202 @@
+"""ctypes binding of libtdgl_hip.so (the C ABI declared in include/tdgl_hip.h).
+
+There is deliberately no fallback: if the library is missing or no MI355X is visible, the
+product path raises.  (The NumPy oracle under /oracle is test infrastructure only and is
+never imported from here.)
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtdgl_hip.so")
+
+TDGL_OK = 0
+TDGL_ERR_HIP = 1
+TDGL_ERR_ARG = 2
+TDGL_ERR_PSI_RETRIES = 3
+TDGL_ERR_PCG = 4
+TDGL_ERR_NOT_READY = 5
+
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("n_sites", C.c_int64),
+        ("n_edges", C.c_int64),
+        ("n_boundary_edges", C.c_int64),
+        ("edges", c_i32p),
+        ("areas", c_f64p),
+        ("edge_lengths", c_f64p),
+        ("dual_edge_lengths", c_f64p),
+        ("directions", c_f64p),
+        ("boundary_edge_indices", c_i32p),
+        ("fixed_sites", c_i32p),
+        ("n_fixed", C.c_int64),
+        ("fix_psi", C.c_int32),
+        ("site_perm", c_i32p),
+        ("u", C.c_double),
+        ("gamma", C.c_double),
+    ]
+
+
+class AmgLevel(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64),
+        ("n_coarse", C.c_int64),
+        ("A_indptr", c_i32p),
+        ("A_indices", c_i32p),
+        ("A_data", c_f64p),
+        ("dinv", c_f64p),
+        ("rho", C.c_double),
+        ("P_indptr", c_i32p),
+        ("P_indices", c_i32p),
+        ("P_data", c_f64p),
+        ("R_indptr", c_i32p),
+        ("R_indices", c_i32p),
+        ("R_data", c_f64p),
+    ]
+
+
+class Controller(C.Structure):
+    _fields_ = [
+        ("dt_init", C.c_double),
+        ("dt_max", C.c_double),
+        ("adaptive", C.c_int32),
+        ("adaptive_window", C.c_int32),
+        ("max_solve_retries", C.c_int32),
+        ("adaptive_time_step_multiplier", C.c_double),
+    ]
+
+
+class PoissonOptions(C.Structure):
+    _fields_ = [
+        ("rtol", C.c_double),
+        ("max_iter", C.c_int32),
+        ("nu", C.c_int32),
+        ("check_every", C.c_int32),
+        ("edge_currents_every_step", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); also the list of symbols the header declares
+_CTX = C.c_void_p
+SIGNATURES = {
+    "tdgl_device_count": (C.c_int, []),
+    "tdgl_version": (C.c_char_p, []),
+    "tdgl_last_error": (C.c_char_p, [_CTX]),
+    "tdgl_create": (C.c_int, [C.POINTER(_CTX), C.POINTER(MeshDesc), C.c_int]),
+    "tdgl_destroy": (None, [_CTX]),
+    "tdgl_synchronize": (C.c_int, [_CTX]),
+    "tdgl_poisson_set_hierarchy": (C.c_int, [_CTX, C.POINTER(AmgLevel), C.c_int32, c_f64p]),
+    "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
+    "tdgl_set_link_exponents": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_set_epsilon": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_set_mu_boundary": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_set_state": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_set_controller": (C.c_int, [_CTX, C.POINTER(Controller)]),
+    "tdgl_set_probes": (C.c_int, [_CTX, c_i32p, C.c_int32]),
+    "tdgl_begin_stage": (C.c_int, [_CTX]),
+    "tdgl_run": (
+        C.c_int,
+        [_CTX, C.c_int64, C.c_double, c_f64p, c_f64p, c_f64p, c_i32p,
+         C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
+    ),
+    "tdgl_get_loop_state": (
+        C.c_int,
+        [_CTX, C.POINTER(C.c_int64), c_f64p, c_f64p, c_f64p],
+    ),
+    "tdgl_set_loop_state": (C.c_int, [_CTX, C.c_int64, C.c_double, C.c_double]),
+    "tdgl_get_state": (C.c_int, [_CTX, c_f64p, c_f64p, c_f64p, c_f64p]),
+    "tdgl_apply_psi_laplacian": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_supercurrent": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_psi_update": (
+        C.c_int, [_CTX, c_f64p, c_f64p, C.c_double, c_f64p, c_f64p, C.POINTER(C.c_int32)]
+    ),
+    "tdgl_poisson_rhs": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_poisson_solve": (C.c_int, [_CTX, c_f64p, c_f64p, C.POINTER(C.c_int32), c_f64p]),
+    "tdgl_normal_current": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_vcycle": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_time_kernel": (C.c_int, [_CTX, C.c_int32, C.c_int32, c_f64p]),
+    "tdgl_profile_enable": (C.c_int, [_CTX, C.c_int32]),
+    "tdgl_profile_read": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
+}
+
+_lib = None
+
+
+class TDGLLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libtdgl_hip.so (once).  Raises TDGLLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TDGLLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g;"
+            " g.build()'` (hipcc --offload-arch=gfx950).  tdgl_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    return int(load().tdgl_device_count())
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise TDGLLibraryError(
+            "No HIP device is visible: tdgl_amd runs on MI355X (gfx950) only and has no CPU"
+            " fallback."
+        )
+
+
+# ---- array marshalling helpers ---------------------------------------------------------
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def p_f64(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"] and a.dtype in (np.float64, np.complex128)
+    return a.ctypes.data_as(c_f64p)
+
+
+def p_i32(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"] and a.dtype == np.int32
+    return a.ctypes.data_as(c_i32p)
+
+
+def check(status, ctx=None):
+    """Translate a tdgl_status into the exception the reference would raise."""
+    if status == TDGL_OK:
+        return
+    msg = load().tdgl_last_error(ctx)
+    msg = msg.decode() if msg else f"tdgl status {status}"
+    if status == TDGL_ERR_ARG:
+        raise ValueError(msg)
+    raise RuntimeError(msg)  # PSI_RETRIES carries the reference's wording (solver.py:479-483)

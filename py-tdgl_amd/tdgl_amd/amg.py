@@ -1,0 +1,250 @@
+"""Smoothed-aggregation AMG hierarchy SETUP for the mu Poisson problem (host side).
+
+The reference factorises the (singular, pure-Neumann) mu Laplacian once with SuperLU and
+back-substitutes every step (`tdgl/finite_volume/operators.py:305-308`,
+`tdgl/solver/solver.py:516`).  A sparse direct solve does not map to the GPU; the HIP path
+solves the symmetrised system
+
+    A mu = b,   A = -diag(a) L_mu  (symmetric positive semi-definite, null space = constants),
+                b = -a * rhs
+
+with conjugate gradients preconditioned by one AMG V-cycle.  This module is the analogue of
+the factorisation: it runs once per mesh on the host and produces the level matrices the
+HIP kernels consume (`csrc/poisson.hip`).  The cycle itself never runs on the host in the
+product path.
+
+Algorithm (Vanek/Mandel/Brezina smoothed aggregation with the constant as the only
+near-null-space vector):
+
+* strength graph: all off-diagonal couplings with ``|a_ij| >= theta*sqrt(a_ii a_jj)``;
+* aggregation: roots = a distance-2 maximal independent set (parallel Luby rounds with
+  hashed priorities, deterministic); every other node joins the root reached through its
+  strongest connection (distance 1 first, then distance 2);
+* tentative prolongator T = aggregate indicator (unnormalised, so T 1_c = 1 and the coarse
+  null space is again the constant vector);
+* P = (I - omega/rho(D^-1 A) * D^-1 A) T,  A_c = P^T A P;
+* recursion until n_c <= max_coarse; the coarsest operator gets a dense pseudo-inverse.
+"""
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def _rowmax(indptr, vals, empty=-np.inf):
+    """Row-wise max of CSR-ordered ``vals`` (rows may be empty)."""
+    n = len(indptr) - 1
+    out = np.full(n, empty, dtype=vals.dtype)
+    nonempty = indptr[1:] > indptr[:-1]
+    if len(vals):
+        red = np.maximum.reduceat(vals, indptr[:-1][nonempty])
+        out[nonempty] = red
+    return out
+
+
+def _hash_priority(n, level_seed):
+    """Deterministic pseudo-random distinct priorities (a permutation of 1..n)."""
+    rng = np.random.default_rng(12345 + level_seed)
+    return (rng.permutation(n) + 1).astype(np.int64)
+
+
+def mis2_aggregate(S: sp.csr_matrix, seed: int = 0):
+    """Aggregate the nodes of the symmetric strength graph ``S`` (CSR, no diagonal).
+
+    Returns ``(agg[n] int64, n_agg)``.
+    """
+    n = S.shape[0]
+    indptr, indices = S.indptr, S.indices
+    prio = _hash_priority(n, seed)
+    # state: 0 undecided, 1 root, -1 excluded (within distance 2 of a root)
+    state = np.zeros(n, dtype=np.int8)
+    isolated = indptr[1:] == indptr[:-1]
+    state[isolated] = 1  # isolated nodes are their own aggregates
+    for _ in range(200):
+        und = state == 0
+        if not und.any():
+            break
+        p = np.where(und, prio, 0)
+        m1 = np.maximum(p, _rowmax(indptr, p[indices], empty=0))
+        m2 = np.maximum(m1, _rowmax(indptr, m1[indices], empty=0))
+        new_root = und & (p == m2)
+        state[new_root] = 1
+        r = new_root.astype(np.int8)
+        d1 = np.maximum(r, _rowmax(indptr, r[indices], empty=0))
+        d2 = np.maximum(d1, _rowmax(indptr, d1[indices], empty=0))
+        state[(d2 > 0) & (state == 0)] = -1
+    else:  # pragma: no cover
+        raise RuntimeError("MIS(2) did not terminate")
+    roots = np.flatnonzero(state == 1)
+    n_agg = len(roots)
+    agg = np.full(n, -1, dtype=np.int64)
+    agg[roots] = np.arange(n_agg)
+    w = np.abs(S.data)
+    # distance-1: join the adjacent root with the strongest coupling
+    for _pass in range(2):
+        nbr_agg = agg[indices]
+        score = np.where(nbr_agg >= 0, w, -1.0)
+        best = _rowmax(indptr, score, empty=-1.0)
+        todo = (agg < 0) & (best >= 0)
+        if not todo.any():
+            break
+        # position of the best entry in each row
+        row_of = np.repeat(np.arange(n), np.diff(indptr))
+        is_best = (score == best[row_of]) & todo[row_of]
+        pos = np.flatnonzero(is_best)
+        # first best per row
+        first = np.ones(len(pos), dtype=bool)
+        first[1:] = row_of[pos][1:] != row_of[pos][:-1]
+        pos = pos[first]
+        new_agg = agg.copy()
+        new_agg[row_of[pos]] = nbr_agg[pos]
+        agg = new_agg
+    left = np.flatnonzero(agg < 0)
+    if len(left):  # cannot happen for a maximal MIS(2); keep robust
+        agg[left] = n_agg + np.arange(len(left))
+        n_agg += len(left)
+    return agg, n_agg
+
+
+def estimate_rho_DinvA(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 20, seed: int = 0):
+    """Largest eigenvalue of D^-1 A by power iteration on the symmetrised operator."""
+    n = A.shape[0]
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(n)
+    sq = np.sqrt(dinv)
+    lam = 1.0
+    for _ in range(iters):
+        x /= np.linalg.norm(x)
+        y = sq * (A @ (sq * x))
+        lam = float(x @ y)
+        x = y
+    return lam
+
+
+@dataclass
+class Level:
+    A: sp.csr_matrix
+    dinv: np.ndarray
+    rho: float
+    P: Optional[sp.csr_matrix] = None  # n_l x n_{l+1}
+    R: Optional[sp.csr_matrix] = None  # n_{l+1} x n_l  (= P^T, stored CSR)
+    agg: Optional[np.ndarray] = None
+
+
+@dataclass
+class Hierarchy:
+    levels: List[Level] = field(default_factory=list)
+    coarse_pinv: Optional[np.ndarray] = None  # dense pseudo-inverse of the last level
+
+    @property
+    def sizes(self):
+        return [lv.A.shape[0] for lv in self.levels]
+
+    @property
+    def operator_complexity(self):
+        return sum(lv.A.nnz for lv in self.levels) / self.levels[0].A.nnz
+
+
+def build_hierarchy(
+    A: sp.spmatrix,
+    max_coarse: int = 600,
+    max_levels: int = 12,
+    theta: float = 0.0,
+    omega: float = 4.0 / 3.0,
+) -> Hierarchy:
+    """Build the SA-AMG hierarchy for a symmetric positive semi-definite ``A`` whose null
+    space is the constant vector."""
+    A = sp.csr_matrix(A, dtype=float)
+    A.sum_duplicates()
+    A.sort_indices()
+    h = Hierarchy()
+    for lvl in range(max_levels):
+        n = A.shape[0]
+        diag = A.diagonal()
+        dinv = np.where(diag > 0, 1.0 / np.where(diag > 0, diag, 1.0), 0.0)
+        rho = 1.05 * estimate_rho_DinvA(A, dinv, seed=lvl)
+        level = Level(A=A, dinv=dinv, rho=rho)
+        h.levels.append(level)
+        if n <= max_coarse or lvl == max_levels - 1:
+            break
+        # strength graph
+        C = A.tocoo()
+        off = C.row != C.col
+        keep = off & (np.abs(C.data) >= theta * np.sqrt(np.abs(diag[C.row] * diag[C.col])))
+        keep &= C.data != 0
+        S = sp.csr_matrix((C.data[keep], (C.row[keep], C.col[keep])), shape=A.shape)
+        S.sort_indices()
+        agg, n_agg = mis2_aggregate(S, seed=lvl)
+        if n_agg >= n:  # no coarsening possible
+            break
+        T = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, n_agg))
+        DinvA = sp.diags(dinv) @ A
+        P = (T - (omega / rho) * (DinvA @ T)).tocsr()
+        P.sort_indices()
+        R = P.T.tocsr()
+        R.sort_indices()
+        level.P, level.R, level.agg = P, R, agg
+        A = (R @ A @ P).tocsr()
+        A.sum_duplicates()
+        A.sort_indices()
+        # symmetrise round-off
+        A = ((A + A.T) * 0.5).tocsr()
+        A.sort_indices()
+    last = h.levels[-1].A.toarray()
+    nc = last.shape[0]
+    # pseudo-inverse on the complement of the constant vector
+    J = np.full((nc, nc), 1.0 / nc)
+    h.coarse_pinv = np.linalg.inv(last + J) - J
+    return h
+
+
+# ---------------------------------------------------------------------------------------
+# Host-side reference application of the cycle.  Used by the CPU tests to validate the
+# hierarchy and to cross-check the HIP V-cycle; the product path never calls it.
+def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 1, lvl: int = 0) -> np.ndarray:
+    level = h.levels[lvl]
+    if lvl == len(h.levels) - 1:
+        return h.coarse_pinv @ b
+    A, dinv = level.A, level.dinv
+    w = (4.0 / 3.0) / level.rho
+    x = w * dinv * b
+    for _ in range(nu - 1):
+        x = x + w * dinv * (b - A @ x)
+    r = b - A @ x
+    xc = vcycle_host(h, level.R @ r, nu, lvl + 1)
+    x = x + level.P @ xc
+    for _ in range(nu):
+        x = x + w * dinv * (b - A @ x)
+    return x
+
+
+def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=1):
+    """Preconditioned CG on the semi-definite system (b is projected onto range(A))."""
+    n = len(b)
+    b = b - b.mean()
+    x = np.zeros(n) if x0 is None else x0 - np.mean(x0)
+    r = b - A @ x
+    bnorm = np.linalg.norm(b)
+    if bnorm == 0:
+        return x, 0, 0.0
+    z = vcycle_host(h, r, nu)
+    p = z.copy()
+    rz = r @ z
+    res = np.linalg.norm(r) / bnorm
+    it = 0
+    while res > rtol and it < maxiter:
+        q = A @ p
+        alpha = rz / (p @ q)
+        x += alpha * p
+        r -= alpha * q
+        res = np.linalg.norm(r) / bnorm
+        it += 1
+        if res <= rtol:
+            break
+        z = vcycle_host(h, r, nu)
+        rz_new = r @ z
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+    return x - x.mean(), it, res

@@ -1,0 +1,289 @@
+"""Object wrapper over the C ABI (one method per entry point of include/tdgl_hip.h)."""
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+from . import _lib
+from ._lib import c128, f64, i32, p_f64, p_i32
+from .amg import Hierarchy, build_hierarchy
+
+
+def rcm_permutation(edges: np.ndarray, n: int) -> np.ndarray:
+    """Reverse Cuthill-McKee ordering of the site graph: ``perm[k]`` = reference id of the
+    site stored at internal position ``k``."""
+    i, j = edges[:, 0], edges[:, 1]
+    g = sp.csr_matrix(
+        (np.ones(2 * len(edges), dtype=np.int8), (np.concatenate([i, j]), np.concatenate([j, i]))),
+        shape=(n, n),
+    )
+    return np.ascontiguousarray(reverse_cuthill_mckee(g, symmetric_mode=True), dtype=np.int32)
+
+
+def poisson_matrix(edges, weights, n, iperm=None) -> sp.csr_matrix:
+    """``A = -diag(a) L_mu``: ``A_ij = -w_ij``, ``A_ii = sum_j w_ij`` with
+    ``w = dual_edge_lengths / edge_lengths`` (reference L_mu: operators.py:120-185 with
+    U = 1, no fixed sites, operators.py:285)."""
+    i, j = edges[:, 0], edges[:, 1]
+    if iperm is not None:
+        i, j = iperm[i], iperm[j]
+    w = np.asarray(weights, dtype=float)
+    A = sp.coo_matrix(
+        (np.concatenate([-w, -w, w, w]), (np.concatenate([i, j, i, j]), np.concatenate([j, i, i, j]))),
+        shape=(n, n),
+    ).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+class TDGLContext:
+    """Owns one ``tdgl_ctx`` (device buffers + stream) for a mesh."""
+
+    def __init__(self, mesh, fixed_sites=None, fix_psi=True, u=5.79, gamma=10.0, device_id=0,
+                 reorder="rcm"):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        em = mesh.edge_mesh
+        self.n = len(mesh.sites)
+        self.m = len(em.edges)
+        self.n_boundary = len(em.boundary_edge_indices)
+        self.n_probe = 0
+        edges = i32(em.edges)
+        if reorder == "rcm":
+            perm = rcm_permutation(em.edges, self.n)
+        elif reorder is None or reorder == "none":
+            perm = np.arange(self.n, dtype=np.int32)
+        else:
+            perm = i32(reorder)
+        self.perm = perm
+        self.iperm = np.empty(self.n, dtype=np.int64)
+        self.iperm[perm] = np.arange(self.n)
+        fixed = i32([] if fixed_sites is None else fixed_sites)
+        self._keep = dict(
+            edges=edges, areas=f64(mesh.areas), el=f64(em.edge_lengths),
+            dl=f64(em.dual_edge_lengths), dirs=f64(em.directions),
+            bidx=i32(em.boundary_edge_indices), fixed=fixed, perm=perm,
+        )
+        k = self._keep
+        desc = _lib.MeshDesc(
+            n_sites=self.n, n_edges=self.m, n_boundary_edges=self.n_boundary,
+            edges=p_i32(k["edges"]), areas=p_f64(k["areas"]), edge_lengths=p_f64(k["el"]),
+            dual_edge_lengths=p_f64(k["dl"]), directions=p_f64(k["dirs"]),
+            boundary_edge_indices=p_i32(k["bidx"]),
+            fixed_sites=p_i32(fixed) if len(fixed) else None, n_fixed=len(fixed),
+            fix_psi=int(bool(fix_psi)), site_perm=p_i32(perm), u=float(u), gamma=float(gamma),
+        )
+        _lib.check(self._lib.tdgl_create(C.byref(self._ctx), C.byref(desc), int(device_id)))
+        self.hierarchy = None
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.tdgl_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, status):
+        _lib.check(status, self._ctx)
+
+    def synchronize(self):
+        self._chk(self._lib.tdgl_synchronize(self._ctx))
+
+    # -- Poisson set-up -------------------------------------------------------------------
+    def build_poisson(self, rtol=1e-10, max_iter=500, nu=1, check_every=1,
+                      edge_currents_every_step=True, max_coarse=600) -> Hierarchy:
+        """AMG set-up on the host (the counterpart of the reference's LU factorisation,
+        operators.py:305-308) + upload."""
+        k = self._keep
+        A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
+        h = build_hierarchy(A, max_coarse=max_coarse)
+        self.set_hierarchy(h)
+        self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step)
+        return h
+
+    def set_hierarchy(self, h: Hierarchy):
+        levels = (_lib.AmgLevel * len(h.levels))()
+        keep = []
+        for idx, lv in enumerate(h.levels):
+            A = lv.A.tocsr()
+            arrs = dict(
+                Ap=i32(A.indptr), Ai=i32(A.indices), Ad=f64(A.data), dinv=f64(lv.dinv)
+            )
+            L = levels[idx]
+            L.n = A.shape[0]
+            L.A_indptr, L.A_indices, L.A_data = p_i32(arrs["Ap"]), p_i32(arrs["Ai"]), p_f64(arrs["Ad"])
+            L.dinv = p_f64(arrs["dinv"])
+            L.rho = float(lv.rho)
+            if lv.P is not None:
+                P, R = lv.P.tocsr(), lv.R.tocsr()
+                arrs.update(Pp=i32(P.indptr), Pi=i32(P.indices), Pd=f64(P.data),
+                            Rp=i32(R.indptr), Ri=i32(R.indices), Rd=f64(R.data))
+                L.n_coarse = P.shape[1]
+                L.P_indptr, L.P_indices, L.P_data = p_i32(arrs["Pp"]), p_i32(arrs["Pi"]), p_f64(arrs["Pd"])
+                L.R_indptr, L.R_indices, L.R_data = p_i32(arrs["Rp"]), p_i32(arrs["Ri"]), p_f64(arrs["Rd"])
+            else:
+                L.n_coarse = 0
+            keep.append(arrs)
+        pinv = f64(h.coarse_pinv)
+        self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
+        self.hierarchy = h
+
+    def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=1, check_every=1,
+                            edge_currents_every_step=True):
+        o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
+                                int(bool(edge_currents_every_step)))
+        self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
+
+    # -- inputs ---------------------------------------------------------------------------
+    def set_link_exponents(self, A):
+        A = f64(A)
+        if A.shape != (self.m, 2):
+            raise ValueError(f"Unexpected shape for vector_potential: {A.shape}.")
+        self._chk(self._lib.tdgl_set_link_exponents(self._ctx, p_f64(A)))
+
+    def set_epsilon(self, eps):
+        eps = f64(np.broadcast_to(eps, (self.n,)))
+        self._chk(self._lib.tdgl_set_epsilon(self._ctx, p_f64(eps)))
+
+    def set_mu_boundary(self, mu_b):
+        mu_b = f64(mu_b)
+        assert mu_b.shape == (self.n_boundary,)
+        self._chk(self._lib.tdgl_set_mu_boundary(self._ctx, p_f64(mu_b)))
+
+    def set_state(self, psi, mu):
+        psi, mu = c128(psi), f64(mu)
+        assert psi.shape == (self.n,) and mu.shape == (self.n,)
+        self._chk(self._lib.tdgl_set_state(self._ctx, p_f64(psi), p_f64(mu)))
+
+    def set_controller(self, dt_init, dt_max, adaptive, adaptive_window, max_solve_retries,
+                       adaptive_time_step_multiplier):
+        c = _lib.Controller(float(dt_init), float(dt_max), int(bool(adaptive)), int(adaptive_window),
+                            int(max_solve_retries), float(adaptive_time_step_multiplier))
+        self._chk(self._lib.tdgl_set_controller(self._ctx, C.byref(c)))
+
+    def set_probes(self, sites):
+        sites = i32([] if sites is None else sites)
+        self.n_probe = len(sites)
+        self._chk(self._lib.tdgl_set_probes(self._ctx, p_i32(sites) if len(sites) else None, len(sites)))
+
+    # -- time loop --------------------------------------------------------------------------
+    def begin_stage(self):
+        self._chk(self._lib.tdgl_begin_stage(self._ctx))
+
+    def run(self, max_steps, end_time=np.inf):
+        """Up to ``max_steps`` iterations of the reference's loop.  Returns a dict with
+        ``dt[k]``, ``mu[k, n_probe]``, ``theta[k, n_probe]``, ``pcg_iters[k]``,
+        ``reached_end``."""
+        max_steps = int(max_steps)
+        dts = np.zeros(max_steps)
+        npb = self.n_probe
+        mu_p = np.zeros((max_steps, npb)) if npb else None
+        th_p = np.zeros((max_steps, npb)) if npb else None
+        iters = np.zeros(max_steps, dtype=np.int32)
+        done, reached = C.c_int64(0), C.c_int32(0)
+        status = self._lib.tdgl_run(
+            self._ctx, max_steps, float(end_time), p_f64(dts), p_f64(mu_p), p_f64(th_p),
+            p_i32(iters), C.byref(done), C.byref(reached),
+        )
+        self._chk(status)
+        k = done.value
+        return dict(
+            dt=dts[:k], mu=None if mu_p is None else mu_p[:k],
+            theta=None if th_p is None else th_p[:k], pcg_iters=iters[:k],
+            reached_end=bool(reached.value),
+        )
+
+    def loop_state(self):
+        step, t, rdt, tdt = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        self._chk(self._lib.tdgl_get_loop_state(self._ctx, C.byref(step), C.byref(t), C.byref(rdt), C.byref(tdt)))
+        return dict(step=step.value, time=t.value, dt=rdt.value, tentative_dt=tdt.value)
+
+    def set_loop_state(self, step, time, runner_dt):
+        self._chk(self._lib.tdgl_set_loop_state(self._ctx, int(step), float(time), float(runner_dt)))
+
+    def get_state(self, psi=True, mu=True, supercurrent=True, normal_current=True):
+        out = {}
+        a_psi = np.empty(self.n, dtype=np.complex128) if psi else None
+        a_mu = np.empty(self.n) if mu else None
+        a_js = np.empty(self.m) if supercurrent else None
+        a_jn = np.empty(self.m) if normal_current else None
+        self._chk(self._lib.tdgl_get_state(self._ctx, p_f64(a_psi), p_f64(a_mu), p_f64(a_js), p_f64(a_jn)))
+        if psi:
+            out["psi"] = a_psi
+        if mu:
+            out["mu"] = a_mu
+        if supercurrent:
+            out["supercurrent"] = a_js
+        if normal_current:
+            out["normal_current"] = a_jn
+        return out
+
+    # -- single operators ---------------------------------------------------------------------
+    def apply_psi_laplacian(self, psi):
+        psi = c128(psi)
+        out = np.empty(self.n, dtype=np.complex128)
+        self._chk(self._lib.tdgl_apply_psi_laplacian(self._ctx, p_f64(psi), p_f64(out)))
+        return out
+
+    def supercurrent(self, psi):
+        psi = c128(psi)
+        out = np.empty(self.m)
+        self._chk(self._lib.tdgl_supercurrent(self._ctx, p_f64(psi), p_f64(out)))
+        return out
+
+    def normal_current(self, mu):
+        mu = f64(mu)
+        out = np.empty(self.m)
+        self._chk(self._lib.tdgl_normal_current(self._ctx, p_f64(mu), p_f64(out)))
+        return out
+
+    def psi_update(self, psi, mu, dt):
+        """Returns ``(psi_new, abs_sq_new)`` or ``None`` (like solve_for_psi_squared)."""
+        psi, mu = c128(psi), f64(mu)
+        out = np.empty(self.n, dtype=np.complex128)
+        sq = np.empty(self.n)
+        ok = C.c_int32(0)
+        self._chk(self._lib.tdgl_psi_update(self._ctx, p_f64(psi), p_f64(mu), float(dt), p_f64(out), p_f64(sq), C.byref(ok)))
+        return (out, sq) if ok.value else None
+
+    def poisson_rhs(self, psi):
+        psi = c128(psi)
+        out = np.empty(self.n)
+        self._chk(self._lib.tdgl_poisson_rhs(self._ctx, p_f64(psi), p_f64(out)))
+        return out
+
+    def poisson_solve(self, rhs, mu0=None):
+        rhs = f64(rhs)
+        mu = np.zeros(self.n) if mu0 is None else f64(mu0).copy()
+        it, rel = C.c_int32(0), C.c_double(0)
+        self._chk(self._lib.tdgl_poisson_solve(self._ctx, p_f64(rhs), p_f64(mu), C.byref(it), C.byref(rel)))
+        return mu, it.value, rel.value
+
+    def vcycle(self, r):
+        r = f64(r)
+        z = np.empty(self.n)
+        self._chk(self._lib.tdgl_vcycle(self._ctx, p_f64(r), p_f64(z)))
+        return z
+
+    # -- measurement -----------------------------------------------------------------------------
+    def time_kernel(self, kernel: int, reps: int = 20) -> float:
+        ms = C.c_double(0)
+        self._chk(self._lib.tdgl_time_kernel(self._ctx, int(kernel), int(reps), C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._chk(self._lib.tdgl_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_read(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        self._chk(self._lib.tdgl_profile_read(self._ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value

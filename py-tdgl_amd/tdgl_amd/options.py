@@ -1,0 +1,106 @@
+"""Solver options: same field names, defaults and validation messages as the reference's
+``tdgl.SolverOptions`` (`tdgl/solver/options.py:19-166`), so scripts carry over unchanged.
+
+Differences, all at the backend seam:
+
+* there is exactly one compute path (HIP kernels on MI355X).  ``gpu`` and
+  ``sparse_solver`` are accepted for source compatibility; every value of
+  ``sparse_solver`` selects the AMG-preconditioned CG solve that replaces the reference's
+  sparse LU, and ``gpu`` has no effect (there is no CPU path to fall back to);
+* ``pcg_rtol`` / ``pcg_max_iter`` / ``amg_smoothing_sweeps`` control that solve;
+* ``output_file`` / ``monitor`` need h5py and the reference's viewer, which are out of
+  scope: results are returned in memory (see ``tdgl_amd.solution.Solution``).
+"""
+
+from dataclasses import dataclass
+from enum import Enum
+from typing import Union
+
+
+class SolverOptionsError(ValueError):
+    pass
+
+
+class SparseSolver(Enum):
+    """Names accepted for ``SolverOptions.sparse_solver`` (reference: options.py:10-16) plus
+    the native one.  All of them run the HIP AMG-PCG solve."""
+
+    SUPERLU = "superlu"
+    UMFPACK = "umfpack"
+    PARDISO = "pardiso"
+    CUPY = "cupy"
+    AMG_PCG = "amg_pcg"
+
+
+@dataclass
+class SolverOptions:
+    solve_time: float
+    skip_time: float = 0.0
+    dt_init: float = 1e-6
+    dt_max: float = 1e-1
+    adaptive: bool = True
+    adaptive_window: int = 10
+    max_solve_retries: int = 10
+    adaptive_time_step_multiplier: float = 0.25
+    output_file: Union[str, None] = None
+    terminal_psi: Union[float, complex, None] = 0.0
+    gpu: bool = False
+    sparse_solver: Union[SparseSolver, str] = SparseSolver.SUPERLU
+    pause_on_interrupt: bool = True
+    save_every: int = 100
+    progress_interval: int = 0
+    monitor: bool = False
+    monitor_update_interval: float = 1.0
+    field_units: str = "mT"
+    current_units: str = "uA"
+    include_screening: bool = False
+    max_iterations_per_step: int = 1000
+    screening_tolerance: float = 1e-3
+    screening_step_size: float = 0.1
+    screening_step_drag: float = 0.5
+    # --- native Poisson-solve controls (no reference counterpart) ---
+    pcg_rtol: float = 1e-10
+    pcg_max_iter: int = 500
+    amg_smoothing_sweeps: int = 1
+    edge_currents_every_step: bool = True
+    device_id: int = 0
+
+    def validate(self) -> None:
+        def fail(msg):
+            raise SolverOptionsError(msg)
+
+        if self.dt_init > self.dt_max:
+            fail("dt_init must be less than or equal to dt_max.")
+        tp = self.terminal_psi
+        if tp is not None and not (0 <= abs(tp) <= 1):
+            fail(f"terminal_psi must be None or have absolute value in [0, 1] (got {tp}).")
+        mult = self.adaptive_time_step_multiplier
+        if not (0 < mult < 1):
+            fail(f"adaptive_time_step_multiplier must be in (0, 1) (got {mult}).")
+        if not (0 < self.screening_step_drag <= 1):
+            fail(f"screening_step_drag must be in (0, 1] (got {self.screening_step_drag}).")
+        if self.screening_step_size <= 0:
+            fail(f"screening_step_size must be in > 0 (got {self.screening_step_size}).")
+        if self.screening_tolerance <= 0:
+            fail(f"screening_tolerance must be in > 0 (got {self.screening_tolerance}).")
+        solver = self.sparse_solver
+        if isinstance(solver, str):
+            try:
+                solver = SparseSolver[solver.upper()]
+            except KeyError:
+                valid = list(SparseSolver.__members__.keys())
+                fail(f"sparse solver must be one of {valid!r}, got {solver}.")
+            self.sparse_solver = solver
+        if not isinstance(self.sparse_solver, SparseSolver):
+            fail(f"sparse solver must be a SparseSolver or str, got {self.sparse_solver!r}.")
+        if self.include_screening:
+            fail(
+                "include_screening=True is not supported by the MI355X time-stepping core"
+                " (the reference's dense 1/r kernel, tdgl/solver/screening.py, is out of scope)."
+            )
+        if not (self.pcg_rtol > 0):
+            fail(f"pcg_rtol must be > 0 (got {self.pcg_rtol}).")
+        if self.pcg_max_iter < 1 or self.amg_smoothing_sweeps < 1:
+            fail("pcg_max_iter and amg_smoothing_sweeps must be >= 1.")
+        if self.save_every < 1:
+            fail(f"save_every must be >= 1 (got {self.save_every}).")

@@ -1,0 +1,82 @@
+"""In-memory result of a simulation.
+
+The reference's ``Solution`` (`tdgl/solution/solution.py:59-1090`) wraps an HDF5 file and
+offers post-processing/plotting; that layer is out of scope here (h5py is not on the target
+image).  This class carries what the solver produced: the fields at every saved step, the
+per-step scalars (``dt``, probe ``mu``/``theta``) and the configuration.
+"""
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+
+@dataclass
+class TDGLData:
+    """Fields at one saved step (cf. `tdgl/solution/data.py:69-170`)."""
+
+    step: int
+    time: float
+    dt: float
+    psi: np.ndarray
+    mu: np.ndarray
+    supercurrent: np.ndarray
+    normal_current: np.ndarray
+    applied_vector_potential: Optional[np.ndarray] = None
+    epsilon: Optional[np.ndarray] = None
+
+
+@dataclass
+class DynamicsData:
+    """Per-step scalars of the saved stage (cf. `tdgl/solution/data.py:173-330`)."""
+
+    dt: np.ndarray
+    time: np.ndarray
+    mu: Optional[np.ndarray] = None      # [n_probe, n_steps]
+    theta: Optional[np.ndarray] = None   # [n_probe, n_steps]
+    pcg_iterations: Optional[np.ndarray] = None
+
+    def voltage(self, i: int = 0, j: int = 1) -> np.ndarray:
+        """mu_i - mu_j between two probe points, per step."""
+        return self.mu[i] - self.mu[j]
+
+    def phase_difference(self, i: int = 0, j: int = 1) -> np.ndarray:
+        return np.unwrap(self.theta[i] - self.theta[j])
+
+
+@dataclass
+class Solution:
+    device: object
+    options: object
+    saved_steps: List[TDGLData] = field(default_factory=list)
+    dynamics: Optional[DynamicsData] = None
+    applied_vector_potential: object = None
+    terminal_currents: object = None
+    disorder_epsilon: object = None
+    total_seconds: float = 0.0
+    stats: Dict[str, float] = field(default_factory=dict)
+    solve_step: int = -1
+
+    @property
+    def tdgl_data(self) -> TDGLData:
+        """The saved step selected by ``solve_step`` (default: the last one)."""
+        return self.saved_steps[self.solve_step]
+
+    @property
+    def times(self) -> np.ndarray:
+        return np.array([s.time for s in self.saved_steps])
+
+    def current_through_cut(self, x0: float) -> float:
+        """Total dimensionless sheet current crossing the vertical line x = x0 (in units of
+        xi), summed over the mesh edges that cross it: ``sum_e (J_s + J_n)_e s_e sign`` with
+        ``s_e`` the Voronoi dual length.  Discretely conserved."""
+        mesh = self.device.mesh
+        em = mesh.edge_mesh
+        d = self.tdgl_data
+        xa = mesh.sites[em.edges[:, 0], 0]
+        xb = mesh.sites[em.edges[:, 1], 0]
+        crossing = (xa < x0) != (xb < x0)
+        sign = np.where(xa < x0, 1.0, -1.0)
+        j = (d.supercurrent + d.normal_current) * em.dual_edge_lengths * sign
+        return float(j[crossing].sum())

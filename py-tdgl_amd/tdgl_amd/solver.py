@@ -1,0 +1,415 @@
+"""``TDGLSolver`` / ``solve``: the reference's solver API (`tdgl/solver/solver.py:88-827`,
+`tdgl/solver/solve.py:9-52`) driving the HIP time-stepping core.
+
+What runs where:
+
+* setup (this file, Python): unit scaling of the applied vector potential and terminal
+  currents, epsilon evaluation, terminal detection -- the work of
+  ``TDGLSolver.__init__`` (solver.py:117-323);
+* every time step (libtdgl_hip, C++/HIP): psi update with retries, Poisson solve, currents,
+  probe read-out, adaptive-dt controller and the Runner loop's time/step accounting
+  (``tdgl_run``); Python is entered once per ``save_every`` steps (or once per step when the
+  terminal currents are a function of time, because the callable lives in Python).
+
+Not supported (raise): ``include_screening``, time-dependent ``applied_vector_potential`` /
+``disorder_epsilon``, HDF5 output.
+"""
+
+import inspect
+import logging
+import numbers
+import time as _time
+from typing import Callable, Dict, NamedTuple, Optional, Sequence, Union
+
+import numpy as np
+
+from .device import Device, TerminalInfo
+from .operators import MeshOperators
+from .options import SolverOptions
+from .solution import DynamicsData, Solution, TDGLData
+
+logger = logging.getLogger("solver")
+
+
+def validate_terminal_currents(terminal_currents, terminal_info: Sequence[TerminalInfo],
+                               solver_options: SolverOptions, num_evals: int = 100) -> None:
+    """Terminal currents must name known terminals and sum to zero (solver.py:35-60)."""
+    known = {t.name for t in terminal_info}
+
+    def check(currents: Dict[str, float]):
+        unknown = set(currents).difference(known)
+        if unknown:
+            raise ValueError(f"Unknown terminal(s) in terminal currents: {list(unknown)}.")
+        total = sum(currents.values())
+        if total:
+            raise ValueError(f"The sum of all terminal currents must be 0 (got {total:.2e}).")
+
+    if callable(terminal_currents):
+        for t in np.random.default_rng().random(num_evals) * solver_options.solve_time:
+            check(terminal_currents(t))
+    else:
+        check(terminal_currents)
+
+
+class SolverResult(NamedTuple):
+    """Result of one solve step (same fields as solver.py:63-85)."""
+
+    dt: float
+    psi: np.ndarray
+    mu: np.ndarray
+    supercurrent: np.ndarray
+    normal_current: np.ndarray
+    A_induced: np.ndarray
+    A_applied: Optional[np.ndarray] = None
+    epsilon: Optional[np.ndarray] = None
+
+
+def uniform_field_vector_potential(x, y, B):
+    """Symmetric-gauge vector potential of a uniform field ``B`` (in [field] * [length]),
+    centred on the bounding box of the evaluation points -- what the reference's
+    ``ConstantField`` evaluates (`tdgl/em.py:437-472`, `tdgl/sources/constant.py:7-21`)."""
+    xs = x - (x.min() + np.ptp(x) / 2)
+    ys = y - (y.min() + np.ptp(y) / 2)
+    return np.stack([-B * ys / 2, B * xs / 2, np.zeros_like(xs)], axis=1)
+
+
+class TDGLSolver:
+    """Solver for a TDGL model; same constructor as the reference (solver.py:117-125)."""
+
+    def __init__(
+        self,
+        device: Device,
+        options: SolverOptions,
+        applied_vector_potential: Union[Callable, float] = 0.0,
+        terminal_currents: Union[Callable, Dict[str, float], None] = None,
+        disorder_epsilon: Union[Callable, float] = 1.0,
+        seed_solution: Optional[Solution] = None,
+    ):
+        self.device = device
+        self.options = options
+        options.validate()
+        self.terminal_currents = terminal_currents
+        self.seed_solution = seed_solution
+        if device.mesh is None:
+            raise ValueError("The device has no mesh: call device.make_mesh() first.")
+        mesh = device.mesh
+        em = mesh.edge_mesh
+        xi = device.coherence_length
+        self.u, self.gamma = device.layer.u, device.layer.gamma
+        self.probe_points = device.probe_point_indices
+        self.num_edges = len(em.edges)
+        self.sites = xi * mesh.sites
+        self.edge_centers = xi * em.centers
+        self.z0 = device.layer.z0 * np.ones(len(self.edge_centers))
+
+        # ---- applied vector potential on the edges (solver.py:158-189) ------------------
+        self.dynamic_vector_potential = bool(
+            getattr(applied_vector_potential, "time_dependent", False)
+        )
+        if self.dynamic_vector_potential:
+            raise NotImplementedError(
+                "Time-dependent applied vector potentials are not supported yet."
+            )
+        self.applied_vector_potential = applied_vector_potential
+        self.A_scale = device.field_scale(options.field_units)
+        ex, ey = self.edge_centers[:, 0], self.edge_centers[:, 1]
+        if callable(applied_vector_potential):
+            A = np.asarray(applied_vector_potential(ex, ey, self.z0))
+        else:
+            A = uniform_field_vector_potential(ex, ey, float(applied_vector_potential))
+        A = self.A_scale * np.asarray(A)[:, :2]
+        if A.shape != self.edge_centers.shape:
+            raise ValueError(f"Unexpected shape for vector_potential: {A.shape}.")
+        self.current_A_applied = A
+
+        # ---- disorder parameter epsilon on the sites (solver.py:191-216) ----------------
+        if callable(disorder_epsilon):
+            spec = inspect.getfullargspec(disorder_epsilon)
+            if "t" in spec.kwonlyargs:
+                raise NotImplementedError("Time-dependent disorder_epsilon is not supported yet.")
+            vectorized = spec.kwonlydefaults is not None and spec.kwonlydefaults.get("vectorized", False)
+            if vectorized:
+                epsilon = np.asarray(disorder_epsilon(self.sites), dtype=float)
+            else:
+                epsilon = np.array([float(disorder_epsilon(r)) for r in self.sites])
+        else:
+            epsilon = float(disorder_epsilon) * np.ones(len(self.sites))
+        if np.any(epsilon > 1):
+            raise ValueError("The disorder parameter epsilon must be <= 1")
+        self.dynamic_epsilon = False
+        self.disorder_epsilon = disorder_epsilon
+        self.epsilon = epsilon
+
+        # ---- terminals and currents (solver.py:224-265) ------------------------------------
+        self.terminal_info = device.terminal_info()
+        self.terminal_names = [t.name for t in self.terminal_info]
+        for t in self.terminal_info:
+            if t.length == 0:
+                raise ValueError(
+                    f"Terminal {t.name!r} does not contain any points on the boundary of the mesh."
+                )
+        if terminal_currents and device.probe_points is None:
+            logger.warning("The terminal currents are non-null, but the device has no probe points.")
+        names = self.terminal_names
+        self.dynamic_currents = callable(terminal_currents)
+        if terminal_currents is None:
+            terminal_currents = {name: 0 for name in names}
+        if self.dynamic_currents:
+            raw_func = terminal_currents
+        else:
+            const = {name: terminal_currents.get(name, 0) for name in names}
+            unknown = set(terminal_currents).difference(names)
+            if unknown:
+                raise ValueError(f"Unknown terminal(s) in terminal currents: {list(unknown)}.")
+
+            def raw_func(t):
+                return const
+
+        J_scale = device.current_scale(options.current_units)
+        self.current_func = lambda t: {k: J_scale * v for k, v in raw_func(t).items()}
+        validate_terminal_currents(self.current_func, self.terminal_info, options)
+        self._setup(mesh)
+
+    @classmethod
+    def from_dimensionless(cls, mesh, options: SolverOptions, link_exponents, epsilon=1.0,
+                           u: float = 5.79, gamma: float = 10.0, terminal_info=(),
+                           current_func=None, probe_points=None, device=None) -> "TDGLSolver":
+        """Build a solver directly from dimensionless inputs -- the arrays the reference's
+        ``__init__`` ends up with (solver.py:185, 214, 225, 254-256): ``A[m, 2]``,
+        ``epsilon[n]``, ``TerminalInfo`` records and ``t -> {name: dimensionless current}``.
+        Used by the parity tests and the benchmark, whose configurations are stated in
+        dimensionless form (b = B/Bc2, xi = 1)."""
+        self = object.__new__(cls)
+        options.validate()
+        self.device = device
+        self.options = options
+        self.terminal_currents = None
+        self.seed_solution = None
+        self.u, self.gamma = u, gamma
+        self.probe_points = None if probe_points is None else [int(p) for p in probe_points]
+        self.num_edges = len(mesh.edge_mesh.edges)
+        self.sites = mesh.sites
+        self.applied_vector_potential = None
+        self.disorder_epsilon = epsilon
+        self.dynamic_vector_potential = self.dynamic_epsilon = False
+        A = np.asarray(link_exponents, dtype=float)
+        if A.shape != (self.num_edges, 2):
+            raise ValueError(f"Unexpected shape for vector_potential: {A.shape}.")
+        self.current_A_applied = A
+        self.epsilon = np.asarray(epsilon, dtype=float) * np.ones(len(mesh.sites))
+        if np.any(self.epsilon > 1):
+            raise ValueError("The disorder parameter epsilon must be <= 1")
+        info = [t if isinstance(t, TerminalInfo) else TerminalInfo(
+            t["name"], t["site_indices"], t.get("edge_indices", []), t["boundary_edge_indices"], t["length"])
+            for t in terminal_info]
+        self.terminal_info = tuple(sorted(info, key=lambda t: t.length))
+        self.terminal_names = [t.name for t in self.terminal_info]
+        self.dynamic_currents = callable(current_func)
+        if not self.dynamic_currents:  # None or a constant {name: current} dict
+            const = {name: 0 for name in self.terminal_names}
+            const.update(current_func or {})
+            current_func = lambda t: const  # noqa: E731
+        self.current_func = current_func
+        validate_terminal_currents(self.current_func, self.terminal_info, options)
+        self._setup(mesh)
+        return self
+
+    def _setup(self, mesh) -> None:
+        """Device-side set-up shared by both constructors (solver.py:258-320)."""
+        options = self.options
+        em = mesh.edge_mesh
+        names = self.terminal_names
+        idx = [np.asarray(t.site_indices) for t in self.terminal_info]
+        self.fixed_sites = np.concatenate(idx).astype(np.int64) if idx else np.array([], dtype=np.int64)
+        self.terminal_current_densities = {name: 0 for name in names}
+
+        # ---- operators on the device (solver.py:267-282) --------------------------------------
+        terminal_psi = options.terminal_psi
+        self.operators = MeshOperators(
+            mesh,
+            options.sparse_solver,
+            fixed_sites=self.fixed_sites,
+            fix_psi=(terminal_psi is not None),
+            u=self.u,
+            gamma=self.gamma,
+            device_id=options.device_id,
+            pcg_rtol=options.pcg_rtol,
+            pcg_max_iter=options.pcg_max_iter,
+            amg_smoothing_sweeps=options.amg_smoothing_sweeps,
+            edge_currents_every_step=options.edge_currents_every_step,
+        )
+        self.operators.build_operators()
+        self.operators.set_link_exponents(self.current_A_applied)
+        self.ctx = self.operators.ctx
+
+        # ---- initial values (solver.py:284-289) ------------------------------------------------
+        self.psi_init = np.ones(len(mesh.sites), dtype=np.complex128)
+        if terminal_psi is not None:
+            self.psi_init[self.fixed_sites] = terminal_psi
+        self.mu_init = np.zeros(len(mesh.sites))
+        self.mu_boundary = np.zeros(len(em.boundary_edge_indices))
+        self.ctx.set_epsilon(self.epsilon)
+        self.ctx.set_mu_boundary(self.mu_boundary)
+        self.ctx.set_probes(self.probe_points)
+        self.ctx.set_controller(
+            options.dt_init, options.dt_max, options.adaptive, options.adaptive_window,
+            options.max_solve_retries, options.adaptive_time_step_multiplier,
+        )
+        self._device_holds = None  # (psi, mu) arrays known to equal the device state
+
+    # -- boundary conditions --------------------------------------------------------------------
+    def update_mu_boundary(self, time: float) -> bool:
+        """solver.py:325-345.  Returns True if mu_boundary changed (and was re-uploaded)."""
+        currents = self.current_func(time)
+        changed = False
+        for term in self.terminal_info:
+            density = (-1 / term.length) * sum(
+                currents.get(name, 0) for name in self.terminal_names if name != term.name
+            )
+            if density != self.terminal_current_densities[term.name]:
+                self.terminal_current_densities[term.name] = density
+                self.mu_boundary[term.boundary_edge_indices] = density
+                changed = True
+        if changed:
+            self.ctx.set_mu_boundary(self.mu_boundary)
+        return changed
+
+    # -- one step through the reference's method seam ---------------------------------------------
+    def update(self, state: Dict[str, numbers.Real], running_state, dt: float, *, psi, mu,
+               supercurrent=None, normal_current=None, induced_vector_potential=None,
+               applied_vector_potential=None, epsilon=None) -> SolverResult:
+        """One call of ``TDGLSolver.update`` (solver.py:580-714).
+
+        Compatibility entry point: the fields travel host -> device -> host on every call.
+        ``solve()`` does not use it; it keeps the state resident and batches steps.
+        """
+        ctx = self.ctx
+        held = self._device_holds
+        if held is None or held[0] is not psi or held[1] is not mu:
+            ctx.set_state(psi, mu)
+        ctx.set_loop_state(state["step"], state["time"], state.get("dt", dt))
+        self.update_mu_boundary(state["time"])
+        res = ctx.run(1, np.inf)
+        out = ctx.get_state()
+        self._device_holds = (out["psi"], out["mu"])
+        step_dt = float(res["dt"][0])
+        if running_state is not None:
+            running_state.append("dt", step_dt)
+            if self.probe_points is not None:
+                running_state.append("mu", res["mu"][0])
+                running_state.append("theta", res["theta"][0])
+        a_ind = (
+            np.zeros((self.num_edges, 2)) if induced_vector_potential is None else induced_vector_potential
+        )
+        return SolverResult(step_dt, out["psi"], out["mu"], out["supercurrent"], out["normal_current"], a_ind)
+
+    # -- the whole simulation ------------------------------------------------------------------------
+    def solve(self) -> Optional[Solution]:
+        """Run thermalisation + simulation stages with the reference's loop semantics
+        (runner.py:288-454) and return the saved steps in memory."""
+        opts = self.options
+        opts.validate()
+        ctx = self.ctx
+        t_start = _time.perf_counter()
+        if self.seed_solution is None:
+            psi0, mu0 = self.psi_init, self.mu_init
+        else:
+            if self.seed_solution.device is not self.device:
+                raise ValueError("The seed_solution.device must be equal to the device being simulated.")
+            seed = self.seed_solution.tdgl_data
+            psi0, mu0 = seed.psi, seed.mu
+        ctx.set_state(psi0, mu0)
+        ctx.set_controller(
+            opts.dt_init, opts.dt_max, opts.adaptive, opts.adaptive_window,
+            opts.max_solve_retries, opts.adaptive_time_step_multiplier,
+        )
+        saved = []
+        dyn = dict(dt=[], time=[], mu=[], theta=[], iters=[])
+        n_steps = {"Thermalizing": 0, "Simulating": 0}
+
+        def save_step():
+            ls = ctx.loop_state()
+            if ls["step"] == 0 and not saved and self.seed_solution is None:
+                js = jn = np.zeros(self.num_edges)  # reference initial values (solver.py:736-737)
+                st = ctx.get_state(supercurrent=False, normal_current=False)
+            else:
+                st = ctx.get_state()
+                js, jn = st["supercurrent"], st["normal_current"]
+            saved.append(TDGLData(ls["step"], ls["time"], ls["dt"], st["psi"], st["mu"], js, jn,
+                                  applied_vector_potential=self.current_A_applied, epsilon=self.epsilon))
+
+        def run_stage(name, end_time, save):
+            ctx.begin_stage()
+            i = 0
+            while True:
+                if save and i % opts.save_every == 0:
+                    save_step()
+                chunk = 1 if self.dynamic_currents else opts.save_every - (i % opts.save_every)
+                self.update_mu_boundary(ctx.loop_state()["time"] if self.dynamic_currents else 0.0)
+                t_before = ctx.loop_state()["time"]
+                res = ctx.run(chunk, end_time)
+                k = len(res["dt"])
+                n_steps[name] += k
+                if save:
+                    dyn["dt"].append(res["dt"])
+                    times = t_before + np.concatenate([[0.0], np.cumsum(res["dt"][:-1])])
+                    dyn["time"].append(times)
+                    dyn["iters"].append(res["pcg_iters"])
+                    if res["mu"] is not None:
+                        dyn["mu"].append(res["mu"])
+                        dyn["theta"].append(res["theta"])
+                if res["reached_end"]:
+                    i += k - 1
+                    break
+                i += k
+            if save and (i % opts.save_every):
+                save_step()
+
+        if opts.skip_time:
+            run_stage("Thermalizing", opts.skip_time, False)
+        run_stage("Simulating", opts.solve_time, True)
+        ctx.synchronize()
+        total = _time.perf_counter() - t_start
+        cat = lambda xs: np.concatenate(xs) if xs else np.array([])  # noqa: E731
+        dynamics = DynamicsData(
+            dt=cat(dyn["dt"]),
+            time=cat(dyn["time"]),
+            mu=cat(dyn["mu"]).T if dyn["mu"] else None,
+            theta=cat(dyn["theta"]).T if dyn["theta"] else None,
+            pcg_iterations=cat(dyn["iters"]),
+        )
+        return Solution(
+            device=self.device,
+            options=opts,
+            saved_steps=saved,
+            dynamics=dynamics,
+            applied_vector_potential=self.applied_vector_potential,
+            terminal_currents=self.terminal_currents,
+            disorder_epsilon=self.disorder_epsilon,
+            total_seconds=total,
+            stats=dict(
+                steps_thermalizing=n_steps["Thermalizing"],
+                steps_simulating=n_steps["Simulating"],
+                mean_pcg_iterations=float(dynamics.pcg_iterations.mean()) if len(dynamics.pcg_iterations) else 0.0,
+            ),
+        )
+
+
+def solve(
+    device: Device,
+    options: SolverOptions,
+    applied_vector_potential: Union[Callable, float] = 0,
+    terminal_currents: Union[Callable, Dict[str, float], None] = None,
+    disorder_epsilon: Union[float, Callable] = 1,
+    seed_solution: Optional[Solution] = None,
+) -> Union[Solution, None]:
+    """Solve a TDGL model (`tdgl.solve`, tdgl/solver/solve.py:9-52)."""
+    solver = TDGLSolver(
+        device=device,
+        options=options,
+        applied_vector_potential=applied_vector_potential,
+        terminal_currents=terminal_currents,
+        disorder_epsilon=disorder_epsilon,
+        seed_solution=seed_solution,
+    )
+    return solver.solve()

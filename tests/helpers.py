@@ -104,7 +104,8 @@ def align_phase(psi, psi_ref):
 
 
 def max_abs(a, b):
-    return float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) if len(a) else 0.0
+    a, b = np.atleast_1d(a), np.atleast_1d(b)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
 
 
 def coo_sorted(mat):
