@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""Benchmark of the TDGL time-stepping hot path (BASELINE.json: "TDGL time-steps/sec on 1M-site
+mesh; achieved HBM GB/s vs roofline").
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one call of the reference's ``TDGLSolver.update`` (psi update with retries, Poisson
+solve for mu, supercurrent + normal current on every edge, probe read-out, adaptive-dt
+controller) on a synthetic square film in a uniform field, fields resident in HBM.  Prints ONE
+JSON line on rank 0.  See DESIGN.md "Measurement" for the byte accounting.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (side in xi, description)           site counts follow SURVEY.md §8(d)
+    "5k": (70.0, "square film 70 xi, 5,791 sites"),
+    "60k": (226.0, "square film 226 xi, 59,377 sites"),
+    "250k": (465.0, "square film 465 xi, 250,510 sites"),
+    "1M": (930.0, "square film 930 xi, 1,000,431 sites"),
+    "4M": (1860.0, "square film 1860 xi, ~4.0M sites"),
+}
+B_FIELD = 0.1  # B / Bc2
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def uniform_A(mesh, b):
+    c = mesh.edge_mesh.centers
+    xc = c[:, 0].min() + np.ptp(c[:, 0]) / 2
+    yc = c[:, 1].min() + np.ptp(c[:, 1]) / 2
+    return np.column_stack([-b * (c[:, 1] - yc) / 2, b * (c[:, 0] - xc) / 2])
+
+
+def algorithmic_bytes(n, m):
+    """SURVEY.md §8(d) / BASELINE.md §4 (canonical CSR, int32 indices, fp64 / complex128)."""
+    nnz = 2 * m + n
+    return {
+        "K1_psi_laplacian_spmv": 20 * nnz + 36 * n,
+        "K2_psi_update": 80 * n,
+        "K3_supercurrent": 40 * m + 16 * n,
+        "K4_div_rhs": 32 * m + 12 * n,
+        "K5_pcg_spmv": 12 * nnz + 20 * n,
+        "K6_normal_current": 36 * m + 8 * n,
+        "copy_c128": 32 * n,
+    }
+
+
+def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40):
+    """Time the oracle (NumPy/SciPy port of the reference step: SuperLU + sparse matvecs) on
+    this host, starting from the GPU run's post-warm-up state.  Setup (operator build, LU
+    factorisation) is excluded, like the GPU path's setup."""
+    from oracle import OracleSolver
+
+    o = SimpleNamespace(skip_time=0.0, terminal_psi=0.0, **opt_kw)
+    t0 = time.perf_counter()
+    solver = OracleSolver(mesh, A, 1.0, 5.79, 10.0, o)
+    setup_s = time.perf_counter() - t0
+    solver.tentative_dt = state["tentative_dt"]
+    psi, mu = state["psi"].copy(), state["mu"].copy()
+    t, dt = state["time"], state["dt"]
+    step0 = 10**6  # past the adaptive window, like the GPU run after warm-up
+    # one untimed step (first-touch effects), then time
+    dt, psi, mu, _, _ = solver.update({"step": step0, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
+    n_done, t_start = 0, time.perf_counter()
+    while n_done < max_steps:
+        dt, psi, mu, _, _ = solver.update({"step": step0 + 1 + n_done, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
+        t += dt
+        n_done += 1
+        if time.perf_counter() - t_start > target_seconds:
+            break
+    elapsed = time.perf_counter() - t_start
+    return dict(
+        value=n_done / elapsed,
+        unit="steps/s",
+        cores=1,
+        kind="port",
+        sample=f"{n_done} steps of the same workload from the GPU run's post-warm-up state; "
+               f"oracle = NumPy/SciPy restatement (scipy SuperLU solve + sparse matvecs, single thread); "
+               f"setup excluded ({setup_s:.0f} s, mostly LU factorisation); host has {os.cpu_count()} logical cores",
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default=os.environ.get("TDGL_BENCH_WORKLOAD", "1M"), choices=list(WORKLOADS))
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--check-every", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--kernel-reps", type=int, default=50)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("gloo")
+
+    from tdgl_amd import SolverOptions, TDGLSolver
+    from tdgl_amd.finite_volume import Mesh
+    from tdgl_amd.meshgen import hex_jitter_points, triangulate
+
+    side, desc = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    pts = hex_jitter_points(side, side)
+    tri = triangulate(pts)
+    mesh = Mesh.from_triangulation(pts, tri)
+    n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
+    log(f"rank {rank}: mesh {n} sites / {m} edges in {time.perf_counter() - t0:.1f} s")
+    A = uniform_A(mesh, B_FIELD)
+    opt_kw = dict(solve_time=1e12, dt_init=1e-4, dt_max=0.1, adaptive=True, adaptive_window=10,
+                  max_solve_retries=10, adaptive_time_step_multiplier=0.25, save_every=10**9)
+    opts = SolverOptions(**opt_kw, pcg_rtol=args.rtol, edge_currents_every_step=True, device_id=local_rank)
+    t0 = time.perf_counter()
+    solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0)
+    ctx = solver.ctx
+    ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=1, check_every=args.check_every,
+                            edge_currents_every_step=True)
+    h = ctx.hierarchy
+    log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- warm-up (untimed) -------------------------------------------------------------
+    warm = ctx.run(args.warmup) if args.warmup > 0 else None
+    barrier()
+    start_state = None
+    if rank == 0 and not args.no_cpu_baseline:
+        st = ctx.get_state(supercurrent=False, normal_current=False)
+        ls = ctx.loop_state()
+        start_state = dict(psi=st["psi"], mu=st["mu"], time=ls["time"], dt=ls["dt"], tentative_dt=ls["tentative_dt"])
+
+    # ---- timed region: exactly K steps -----------------------------------------------------
+    ctx.profile_enable(True)
+    barrier()
+    t_begin = time.perf_counter()
+    res = ctx.run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    assert len(res["dt"]) == args.steps
+    launches, k1_ms = ctx.profile_read()
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    steps_per_s = world * args.steps / elapsed  # replicas: every rank advanced its own film
+    ab = algorithmic_bytes(n, m)
+    k1_avg_ms = k1_ms / max(launches, 1)
+    achieved = ab["K1_psi_laplacian_spmv"] / (k1_avg_ms * 1e-3) / 1e9
+    roofline = dict(
+        bound="hbm",
+        kernel="k_psi_laplacian<true> (SELL-64 covariant-Laplacian SpMV fused with the Poisson right-hand side)",
+        achieved=round(achieved, 1),
+        peak=HBM_PEAK_GBS,
+        unit="GB/s",
+        frac=round(achieved / HBM_PEAK_GBS, 4),
+        traffic=None,
+        algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"],
+        avg_launch_ms=round(k1_avg_ms, 5),
+        launches=launches,
+    )
+    # stand-alone kernel timings (same buffers, back-to-back launches) for the other rows
+    names = {0: "K1_psi_laplacian_spmv", 2: "K2_psi_update", 3: "K3_supercurrent", 4: "K5_pcg_spmv", 6: "copy_c128"}
+    kernels = {}
+    for kid, name in names.items():
+        ms = ctx.time_kernel(kid, args.kernel_reps)
+        nbytes = ab[name] + (ab["K6_normal_current"] if kid == 3 else 0)
+        kernels[name if kid != 3 else "K3+K6_edge_currents"] = dict(
+            ms=round(ms, 5), gbs=round(nbytes / (ms * 1e-3) / 1e9, 1), frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        )
+    vc_ms = ctx.time_kernel(5, 20)
+    out = dict(
+        metric="tdgl_steps_per_sec",
+        value=round(steps_per_s, 3),
+        unit="steps/s",
+        n_gpus=world,
+        steps=args.steps,
+        warmup=args.warmup,
+        ms_per_step=round(1e3 * elapsed / args.steps, 4),
+        higher_is_better=True,
+        scaling="weak",
+        vs_baseline=None,
+        dtype="f64",
+        data="synthetic",
+        config=dict(
+            workload=f"{desc}, uniform field b=B/Bc2={B_FIELD}, adaptive dt (dt_init 1e-4, dt_max 0.1), "
+                     f"PCG rtol {args.rtol:g}, J_s/J_n formed every step",
+            sites=n, edges=m, amg_levels=h.sizes, parallelism="replicas" if world > 1 else "single",
+        ),
+        roofline=roofline,
+        pcg=dict(mean_iterations=round(float(res["pcg_iters"].mean()), 2), max_iterations=int(res["pcg_iters"].max()),
+                 vcycle_ms=round(vc_ms, 4), dt_last=float(res["dt"][-1])),
+        kernels=kernels,
+    )
+    if start_state is not None:
+        log("timing the CPU oracle (LU factorisation first; this takes a while at 1M sites)")
+        out["cpu_baseline"] = cpu_baseline(mesh, A, start_state, opt_kw, target_seconds=args.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(steps_per_s / out["cpu_baseline"]["value"], 1)
+        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,211 @@
+"""CPU-only tests of the host layer: C-ABI surface, options, device/terminals/units, AMG set-up."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from helpers import max_abs, mesh_from_golden, synthetic_mesh, uniform_field_A
+
+
+# ---------------------------------------------------------------- C ABI
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "tdgl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tdgl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    from tdgl_amd import _lib
+
+    ge.build()
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/tdgl_hip.h but not exported"
+    # the ctypes table covers exactly the header
+    assert sorted(_lib.SIGNATURES) == declared
+    assert b"gfx950" in lib.tdgl_version()
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path must raise, not compute on the host."""
+    from tdgl_amd import _lib
+    from tdgl_amd.hipcore import TDGLContext
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.TDGLLibraryError, match="no CPU\\s+fallback"):
+        TDGLContext(synthetic_mesh(10))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "py-tdgl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".inc", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+# ---------------------------------------------------------------- options
+def test_solver_options_defaults_and_validation_messages():
+    from tdgl_amd import SolverOptions, SolverOptionsError, SparseSolver
+
+    o = SolverOptions(solve_time=1.0)
+    assert (o.dt_init, o.dt_max, o.adaptive, o.adaptive_window) == (1e-6, 1e-1, True, 10)
+    assert (o.max_solve_retries, o.adaptive_time_step_multiplier, o.save_every) == (10, 0.25, 100)
+    assert o.terminal_psi == 0.0 and o.field_units == "mT" and o.current_units == "uA"
+    o.validate()
+    with pytest.raises(SolverOptionsError, match="dt_init must be less than or equal to dt_max."):
+        SolverOptions(solve_time=1, dt_init=1.0, dt_max=0.1).validate()
+    with pytest.raises(SolverOptionsError, match="terminal_psi must be None or have absolute value"):
+        SolverOptions(solve_time=1, terminal_psi=2.0).validate()
+    with pytest.raises(SolverOptionsError, match="adaptive_time_step_multiplier must be in \\(0, 1\\)"):
+        SolverOptions(solve_time=1, adaptive_time_step_multiplier=1.5).validate()
+    with pytest.raises(SolverOptionsError, match="sparse solver must be one of"):
+        SolverOptions(solve_time=1, sparse_solver="mumps").validate()
+    o = SolverOptions(solve_time=1, sparse_solver="superlu")
+    o.validate()
+    assert o.sparse_solver is SparseSolver.SUPERLU
+    with pytest.raises(SolverOptionsError, match="include_screening"):
+        SolverOptions(solve_time=1, include_screening=True).validate()
+
+
+# ---------------------------------------------------------------- device, terminals, units
+def _strip_device():
+    from tdgl_amd import Device, Layer, Polygon
+    from tdgl_amd.geometry import box
+
+    layer = Layer(coherence_length=0.5, london_lambda=2.0, thickness=0.1)
+    film = Polygon("film", points=box(30.0, 7.5))
+    source = Polygon("source", points=box(0.2, 7.5, center=(-15.0, 0)))
+    drain = Polygon("drain", points=box(0.2, 7.5, center=(15.0, 0)))
+    dev = Device("strip", layer=layer, film=film, terminals=[source, drain],
+                 probe_points=[(-7.5, 0), (7.5, 0)], length_units="um")
+    dev.make_mesh(max_edge_length=0.5)
+    return dev
+
+
+def test_device_mesh_terminals_and_probes():
+    dev = _strip_device()
+    mesh = dev.mesh
+    assert dev.edge_lengths.max() <= 0.5 * (1 + 1e-9)
+    assert mesh.edge_mesh.dual_edge_lengths.min() > 0 and mesh.areas.min() > 0
+    info = dev.terminal_info()
+    assert [t.name for t in info] in (["source", "drain"], ["drain", "source"])
+    for t in info:
+        x0 = -15.0 if t.name == "source" else 15.0
+        assert np.allclose(dev.points[t.site_indices, 0], x0)
+        assert np.isclose(t.length, 7.5)  # physical length of the terminal's boundary edges
+        bidx = mesh.edge_mesh.boundary_edge_indices
+        assert np.array_equal(bidx[t.boundary_edge_indices], t.edge_indices)
+    p = dev.probe_point_indices
+    assert np.allclose(dev.points[p], [(-7.5, 0), (7.5, 0)], atol=0.5)
+
+
+def test_unit_scales_follow_the_reference_formulas():
+    dev = _strip_device()
+    xi_m, lam_m, d_m = 0.5e-6, 2e-6, 0.1e-6
+    bc2 = 2.067833848e-15 / (2 * np.pi * xi_m**2)
+    assert np.isclose(dev.Bc2, bc2, rtol=1e-12)
+    k0 = 4 * xi_m * bc2 / (1.25663706212e-6 * lam_m**2 / d_m)
+    assert np.isclose(dev.K0, k0, rtol=1e-12)
+    # A_scale = [mT] / (Bc2 * xi)  (solver.py:176-180): B = Bc2 gives b = 1 per unit xi
+    assert np.isclose(dev.field_scale("mT") * (bc2 / 1e-3) * 0.5, 1.0, rtol=1e-12)
+    # J_scale = 4 [uA]/[um] / K0  (solver.py:251-253)
+    assert np.isclose(dev.current_scale("uA"), 4 * (1e-6 / 1e-6) / k0, rtol=1e-12)
+    # the reference's own physical pin: K0 for xi=0.5um? no fixture; check the test_solve.py:176
+    # scale instead: lambda=2, d=0.1, xi=1.5 um (box_device, conftest.py:76-85)
+    from tdgl_amd import Device, Layer, Polygon
+    from tdgl_amd.geometry import box
+
+    d2 = Device("box", layer=Layer(coherence_length=1.5, london_lambda=1.0, thickness=0.1),
+                film=Polygon("f", points=box(10)))
+    assert np.isclose(d2.kappa, 1 / 1.5)
+    assert d2.K0 > 0 and d2.A0 > 0
+    with pytest.raises(ValueError, match="conductivity"):
+        d2.tau0()
+
+
+def test_uniform_field_vector_potential_matches_reference_gauge():
+    from tdgl_amd.solver import uniform_field_vector_potential
+
+    mesh = synthetic_mesh(12, 7)
+    c = mesh.edge_mesh.centers
+    got = uniform_field_vector_potential(c[:, 0], c[:, 1], 0.37)[:, :2]
+    assert max_abs(got, uniform_field_A(mesh, 0.37)) < 1e-15
+    # curl A = B on the mesh: circulation around a triangle = B * area
+    e = mesh.elements[5]
+    pts = mesh.sites[e]
+    area = 0.5 * abs(np.cross(pts[1] - pts[0], pts[2] - pts[0]))
+    circ = 0.0
+    for a, b in ((0, 1), (1, 2), (2, 0)):
+        mid = 0.5 * (pts[a] + pts[b])
+        xc = c[:, 0].min() + np.ptp(c[:, 0]) / 2
+        yc = c[:, 1].min() + np.ptp(c[:, 1]) / 2
+        A_mid = np.array([-0.37 * (mid[1] - yc) / 2, 0.37 * (mid[0] - xc) / 2])
+        circ += A_mid @ (pts[b] - pts[a])
+    assert np.isclose(abs(circ), 0.37 * area, rtol=1e-10)
+
+
+def test_polygon_and_invalid_inputs():
+    from tdgl_amd import Device, Layer, Polygon
+    from tdgl_amd.geometry import box, circle
+
+    sq = Polygon("sq", points=box(2.0))
+    assert sq.is_rectangle() and np.isclose(sq.area, 4.0)
+    assert not Polygon("c", points=circle(1.0)).is_rectangle()
+    assert sq.contains_points([[0, 0], [3, 0]]).tolist() == [True, False]
+    layer = Layer(coherence_length=1, london_lambda=1, thickness=1)
+    with pytest.raises(ValueError, match="unique name"):
+        Device("d", layer=layer, film=sq, terminals=[Polygon("t", points=box(1)), Polygon("t", points=box(1))])
+    with pytest.raises(ValueError, match="must lie within the film"):
+        Device("d", layer=layer, film=sq, probe_points=[(5, 5), (0, 0)])
+    with pytest.raises(NotImplementedError):
+        Device("d", layer=layer, film=Polygon("c", points=circle(3.0))).make_mesh()
+
+
+# ---------------------------------------------------------------- reordering and AMG set-up
+def test_rcm_permutation_reduces_bandwidth():
+    from tdgl_amd.hipcore import rcm_permutation
+
+    mesh = mesh_from_golden(load_golden("mesh_irregular"))
+    e = mesh.edge_mesh.edges
+    perm = rcm_permutation(e, len(mesh.sites))
+    assert sorted(perm.tolist()) == list(range(len(mesh.sites)))
+    iperm = np.empty(len(perm), dtype=np.int64)
+    iperm[perm] = np.arange(len(perm))
+    assert np.abs(iperm[e[:, 0]] - iperm[e[:, 1]]).max() < np.abs(e[:, 0] - e[:, 1]).max()
+
+
+def test_amg_hierarchy_and_host_pcg():
+    from tdgl_amd.amg import build_hierarchy, pcg_host
+    from tdgl_amd.hipcore import poisson_matrix
+
+    mesh = synthetic_mesh(60)
+    em = mesh.edge_mesh
+    A = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, len(mesh.sites))
+    assert abs(A @ np.ones(A.shape[0])).max() < 1e-12  # constants are the null space
+    assert abs(A - A.T).max() < 1e-15
+    h = build_hierarchy(A, max_coarse=200)
+    assert len(h.levels) >= 2 and h.sizes[-1] <= 200 and h.operator_complexity < 1.5
+    for lv in h.levels[:-1]:
+        # the prolongator reproduces constants, so every coarse operator keeps the null space
+        assert abs(lv.P @ np.ones(lv.P.shape[1]) - 1).max() < 1e-12
+        assert abs((lv.R - lv.P.T)).max() == 0
+    for lv in h.levels[1:]:
+        assert abs(lv.A @ np.ones(lv.A.shape[0])).max() < 1e-10
+    rng = np.random.default_rng(0)
+    x_true = rng.normal(size=A.shape[0])
+    x_true -= x_true.mean()
+    x, it, res = pcg_host(A, A @ x_true, h, rtol=1e-12)
+    assert it < 40 and res <= 1e-12
+    assert max_abs(x, x_true) < 1e-8
+    # determinism of the set-up (hashed priorities)
+    h2 = build_hierarchy(A, max_coarse=200)
+    assert h2.sizes == h.sizes and abs(h2.levels[0].P - h.levels[0].P).max() == 0
