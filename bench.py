@@ -105,7 +105,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default=os.environ.get("TDGL_BENCH_WORKLOAD", "1M"), choices=list(WORKLOADS))
     ap.add_argument("--rtol", type=float, default=1e-10)
-    ap.add_argument("--check-every", type=int, default=1)
+    ap.add_argument("--check-every", type=int, default=0, help="0 = auto (predicted)")
+    ap.add_argument("--smoother", default="chebyshev", choices=["chebyshev", "jacobi"])
+    ap.add_argument("--nu", type=int, default=2)
+    ap.add_argument("--no-extrapolate", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
@@ -142,8 +145,9 @@ def main():
     t0 = time.perf_counter()
     solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0)
     ctx = solver.ctx
-    ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=1, check_every=args.check_every,
-                            edge_currents_every_step=True)
+    ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
+                            edge_currents_every_step=True, smoother=args.smoother,
+                            extrapolate=not args.no_extrapolate)
     h = ctx.hierarchy
     log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")
     ctx.set_state(solver.psi_init, solver.mu_init)
@@ -227,7 +231,7 @@ def main():
         data="synthetic",
         config=dict(
             workload=f"{desc}, uniform field b=B/Bc2={B_FIELD}, adaptive dt (dt_init 1e-4, dt_max 0.1), "
-                     f"PCG rtol {args.rtol:g}, J_s/J_n formed every step",
+                     f"PCG rtol {args.rtol:g} ({args.smoother} degree-{args.nu} AMG smoother), J_s/J_n formed every step",
             sites=n, edges=m, amg_levels=h.sizes, parallelism="replicas" if world > 1 else "single",
         ),
         roofline=roofline,

@@ -88,10 +88,15 @@ typedef struct {
 typedef struct {
     double rtol;          /* ||b - A mu||_2 <= rtol * ||b||_2                          */
     int32_t max_iter;
-    int32_t nu;           /* Jacobi sweeps before and after the coarse correction      */
-    int32_t check_every;  /* host convergence checks every this many iterations        */
+    int32_t nu;           /* smoother degree: Chebyshev degree / number of Jacobi sweeps,
+                             before and after the coarse correction                    */
+    int32_t check_every;  /* host convergence check every k PCG iterations; 0 = auto:
+                             first after (previous solve's count - 1), then every one   */
     int32_t edge_currents_every_step; /* 1: J_s, J_n are formed every step like the
                                          reference's update(); 0: only on tdgl_get_state */
+    int32_t smoother;     /* 0 = damped Jacobi, 1 = Chebyshev in D^-1 A                */
+    double cheb_lo;       /* Chebyshev interval [cheb_lo * rho, rho]                   */
+    int32_t extrapolate;  /* 1: initial guess mu^n + (dt'/dt)(mu^n - mu^{n-1})          */
 } tdgl_poisson_options;
 
 /* ------------------------------------------------------------------ lifetime */

@@ -73,7 +73,9 @@ static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indp
                     cols[slot] = indices[indptr[r] + k];
                     if (slot_of_nnz) (*slot_of_nnz)[indptr[r] + k] = slot;
                 } else {
-                    cols[slot] = (int32_t)r;  // padding: own row, value 0
+                    // padding (value 0): repeat the row's first column -- always a valid
+                    // column, also for rectangular operators, and already in cache
+                    cols[slot] = deg > 0 ? indices[indptr[r]] : 0;
                 }
             }
         }
@@ -90,17 +92,6 @@ static int build_sell_f64(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
     std::vector<double> vals(A.pat.n_slots, 0.0);
     for (int64_t k = 0; k < indptr[n_rows]; ++k) vals[slot[k]] = data[k];
     HIP_TRY(ctx, A.vals.upload(vals));
-    return TDGL_OK;
-}
-
-static int upload_csr(tdgl_ctx *ctx, int64_t n_rows, int64_t n_cols, const int32_t *indptr,
-                      const int32_t *indices, const double *data, Csr &M) {
-    M.n_rows = n_rows;
-    M.n_cols = n_cols;
-    M.nnz = indptr[n_rows];
-    HIP_TRY(ctx, M.indptr.upload(std::vector<int32_t>(indptr, indptr + n_rows + 1)));
-    HIP_TRY(ctx, M.indices.upload(std::vector<int32_t>(indices, indices + M.nnz)));
-    HIP_TRY(ctx, M.data.upload(std::vector<double>(data, data + M.nnz)));
     return TDGL_OK;
 }
 
@@ -387,7 +378,7 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
 
 static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
                               double dt, double2 *psi_new, double *abs_sq) {
-    const int grid = std::min<int64_t>(grid_for(ctx->n), 256 * 16);
+    const int grid = std::min<int64_t>(grid_for(ctx->n), 2048);
     hipLaunchKernelGGL(k_psi_update, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->n, psi, mu,
                        ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p);
 }
@@ -462,6 +453,7 @@ extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu
     ctx->have_state = true;
     ctx->lap_valid = false;
     ctx->currents_valid = false;
+    ctx->prev_dt = 0.0;  // no mu history: the next solve starts from mu itself
     return TDGL_OK;
 }
 

@@ -81,23 +81,28 @@ struct Csr {
     DevBuf<double> data;
 };
 
+// Level 0 (rows ~ 10^6, 7 entries each) streams through SELL-64, one lane per row.  Coarse
+// levels and the restriction have few, longer rows: one lane per row would be a single long
+// dependent gather chain per wave, so they use CSR with several lanes per row instead.
 struct AmgLevel {
     int64_t n = 0, n_pad = 0, n_coarse = 0;
-    double rho = 2.0, omega = 2.0 / 3.0;
-    SellF64 A;
+    double rho = 2.0;
+    SellF64 A;                       // level 0
+    Csr Ac;                          // levels >= 1
     DevBuf<double> dinv;
-    Csr P, R;
-    DevBuf<double> xa, xb, b, r;  // level vectors (level 0 borrows b/x from PCG)
+    SellF64 P;                       // prolongation n x n_coarse (level 0)
+    Csr Pc, R;                       // prolongation (levels >= 1); restriction n_coarse x n
+    DevBuf<double> xa, xb, d, b, r;  // level vectors (level 0 borrows b from PCG)
 };
 
 // scalars of the PCG recurrence, resident on the device
-enum Scal { S_RZ = 0, S_PQ, S_RR, S_BB, S_ALPHA, S_BETA, S_SUM, S_COUNT = 8 };
+enum Scal { S_RR = 0, S_BB, S_COUNT = 4 };
 
 // what a step reports back to the host at its synchronisation point
 struct StepStatus {
     int32_t fail_flag;          // psi update: discriminant < 0 or non-finite somewhere
     int32_t pad;
-    unsigned long long dmax_bits;  // max | |psi'|^2 - |psi|^2 | as ordered uint64 bits
+    unsigned long long dmax_bits[8];  // max | |psi'|^2 - |psi|^2 | as ordered uint64 bits, 8 slots
     double scal[S_COUNT];
 };
 
@@ -148,10 +153,12 @@ struct tdgl_ctx {
     std::vector<tdgl::AmgLevel *> levels;
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
-    tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q, pcg_za, pcg_zb;
-    tdgl::DevBuf<double> partials;        // per-block partial sums
-    tdgl::DevBuf<double> scal;            // tdgl::Scal
-    tdgl_poisson_options popt{1e-10, 200, 1, 1, 1};
+    tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
+    tdgl::DevBuf<double> part_rz[2], part_pq, part_rr, part_tmp;  // NB per-workgroup partials each
+    tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
+    tdgl::DevBuf<double> mu_prev;         // mu^{n-1} for the extrapolated initial guess
+    double prev_dt = 0.0;                 // dt of the step that produced mu (0: no history)
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 1};
     int32_t last_pcg_iters = 0;
     double last_relres = 0.0;
 

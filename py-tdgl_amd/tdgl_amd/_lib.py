@@ -80,6 +80,9 @@ class PoissonOptions(C.Structure):
         ("nu", C.c_int32),
         ("check_every", C.c_int32),
         ("edge_currents_every_step", C.c_int32),
+        ("smoother", C.c_int32),
+        ("cheb_lo", C.c_double),
+        ("extrapolate", C.c_int32),
     ]
 
 

@@ -203,24 +203,46 @@ def build_hierarchy(
 # ---------------------------------------------------------------------------------------
 # Host-side reference application of the cycle.  Used by the CPU tests to validate the
 # hierarchy and to cross-check the HIP V-cycle; the product path never calls it.
-def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 1, lvl: int = 0) -> np.ndarray:
+def smoother_coefficients(rho, nu=2, smoother="chebyshev", cheb_lo=0.1):
+    """(c1[k], c2[k]) of the smoothing recurrence d <- c1 d + c2 D^-1 (b - A x), x <- x + d
+    (same numbers as `smoother_coef` in csrc/poisson.inc)."""
+    if smoother == "jacobi":
+        return [0.0] * nu, [(4.0 / 3.0) / rho] * nu
+    hi, lo = rho, cheb_lo * rho
+    theta, delta = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    sigma = theta / delta
+    rho_k = 1.0 / sigma
+    c1, c2 = [0.0], [1.0 / theta]
+    for _ in range(1, nu):
+        rho_new = 1.0 / (2.0 * sigma - rho_k)
+        c1.append(rho_new * rho_k)
+        c2.append(2.0 * rho_new / delta)
+        rho_k = rho_new
+    return c1, c2
+
+
+def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 2, smoother: str = "chebyshev",
+                cheb_lo: float = 0.1, lvl: int = 0) -> np.ndarray:
     level = h.levels[lvl]
     if lvl == len(h.levels) - 1:
         return h.coarse_pinv @ b
     A, dinv = level.A, level.dinv
-    w = (4.0 / 3.0) / level.rho
-    x = w * dinv * b
-    for _ in range(nu - 1):
-        x = x + w * dinv * (b - A @ x)
+    c1, c2 = smoother_coefficients(level.rho, nu, smoother, cheb_lo)
+    d = c2[0] * dinv * b
+    x = d.copy()
+    for k in range(1, nu):
+        d = c1[k] * d + c2[k] * dinv * (b - A @ x)
+        x = x + d
     r = b - A @ x
-    xc = vcycle_host(h, level.R @ r, nu, lvl + 1)
+    xc = vcycle_host(h, level.R @ r, nu, smoother, cheb_lo, lvl + 1)
     x = x + level.P @ xc
-    for _ in range(nu):
-        x = x + w * dinv * (b - A @ x)
+    for k in range(nu):
+        d = c1[k] * d + c2[k] * dinv * (b - A @ x)
+        x = x + d
     return x
 
 
-def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=1):
+def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=2, smoother="chebyshev"):
     """Preconditioned CG on the semi-definite system (b is projected onto range(A))."""
     n = len(b)
     b = b - b.mean()
@@ -229,7 +251,7 @@ def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=1):
     bnorm = np.linalg.norm(b)
     if bnorm == 0:
         return x, 0, 0.0
-    z = vcycle_host(h, r, nu)
+    z = vcycle_host(h, r, nu, smoother)
     p = z.copy()
     rz = r @ z
     res = np.linalg.norm(r) / bnorm
@@ -243,7 +265,7 @@ def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=1):
         it += 1
         if res <= rtol:
             break
-        z = vcycle_host(h, r, nu)
+        z = vcycle_host(h, r, nu, smoother)
         rz_new = r @ z
         p = z + (rz_new / rz) * p
         rz = rz_new

@@ -99,15 +99,17 @@ class TDGLContext:
         self._chk(self._lib.tdgl_synchronize(self._ctx))
 
     # -- Poisson set-up -------------------------------------------------------------------
-    def build_poisson(self, rtol=1e-10, max_iter=500, nu=1, check_every=1,
-                      edge_currents_every_step=True, max_coarse=600) -> Hierarchy:
+    def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
+                      edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
+                      cheb_lo=0.1, extrapolate=True) -> Hierarchy:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
         operators.py:305-308) + upload."""
         k = self._keep
         A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
         h = build_hierarchy(A, max_coarse=max_coarse)
         self.set_hierarchy(h)
-        self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step)
+        self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step,
+                                 smoother, cheb_lo, extrapolate)
         return h
 
     def set_hierarchy(self, h: Hierarchy):
@@ -137,10 +139,15 @@ class TDGLContext:
         self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
         self.hierarchy = h
 
-    def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=1, check_every=1,
-                            edge_currents_every_step=True):
+    def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
+                            edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
+                            extrapolate=True):
+        kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
-                                int(bool(edge_currents_every_step)))
+                                int(bool(edge_currents_every_step)), kind, float(cheb_lo),
+                                int(bool(extrapolate)))
+        self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, check_every=check_every,
+                                    smoother=kind, cheb_lo=cheb_lo, extrapolate=bool(extrapolate))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
 
     # -- inputs ---------------------------------------------------------------------------

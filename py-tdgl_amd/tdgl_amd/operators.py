@@ -50,7 +50,7 @@ class MeshOperators:
         device_id: int = 0,
         pcg_rtol: float = 1e-10,
         pcg_max_iter: int = 500,
-        amg_smoothing_sweeps: int = 1,
+        amg_smoothing_sweeps: int = 2,
         edge_currents_every_step: bool = True,
         reorder="rcm",
     ):

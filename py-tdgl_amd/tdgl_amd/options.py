@@ -61,7 +61,7 @@ class SolverOptions:
     # --- native Poisson-solve controls (no reference counterpart) ---
     pcg_rtol: float = 1e-10
     pcg_max_iter: int = 500
-    amg_smoothing_sweeps: int = 1
+    amg_smoothing_sweeps: int = 2  # Chebyshev degree of the AMG smoother
     edge_currents_every_step: bool = True
     device_id: int = 0
 

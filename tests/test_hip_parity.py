@@ -47,7 +47,7 @@ def small_ctx():
     g = load_golden("operators_small")
     mesh = reference_mesh(load_golden("mesh_small"))
     ctx = TDGLContext(mesh, fixed_sites=g["fixed_sites"], fix_psi=True, u=U_DEFAULT, gamma=GAMMA_DEFAULT)
-    ctx.build_poisson(rtol=1e-12)
+    ctx.build_poisson(rtol=1e-12, max_coarse=100)  # 516 -> ~50 rows: a real two-level cycle
     ctx.set_link_exponents(g["A"])
     yield ctx, mesh, g
     ctx.close()
@@ -134,10 +134,13 @@ def test_vcycle_matches_host_restatement(small_ctx):
     ctx, mesh, g = small_ctx
     r = np.random.default_rng(2).normal(size=ctx.n)
     r -= r.mean()
-    want = np.empty(ctx.n)
-    want[ctx.perm] = vcycle_host(ctx.hierarchy, r[ctx.perm])
-    got = ctx.vcycle(r)
-    assert max_abs(got, want) < 1e-12 * np.abs(want).max()
+    for smoother, nu in (("chebyshev", 2), ("jacobi", 1), ("chebyshev", 3)):
+        ctx.set_poisson_options(rtol=1e-12, nu=nu, smoother=smoother)
+        want = np.empty(ctx.n)
+        want[ctx.perm] = vcycle_host(ctx.hierarchy, r[ctx.perm], nu=nu, smoother=smoother)
+        got = ctx.vcycle(r)
+        assert max_abs(got, want) < 1e-12 * np.abs(want).max(), (smoother, nu)
+    ctx.set_poisson_options(rtol=1e-12)
 
 
 def test_psi_update_matches_reference_including_failures():
