@@ -1,0 +1,167 @@
+"""Domain decomposition of the mesh for one-process-per-GPU runs.
+
+The reference is single-process (no collectives exist).  The stencil is nearest
+neighbour on the site graph, so the mesh is cut into ``world`` compact pieces; each rank owns its
+sites, keeps ghost copies of the neighbouring sites it couples to and every edge with at least
+one owned endpoint (cut edges are duplicated, so J on a cut edge is computed identically on both
+sides).  METIS is not available on the target image; the partitioner is recursive coordinate
+bisection (balanced to one site, compact pieces, cut ~ 2 sqrt(n/P) edges per interface on a
+square film -- what a k-way graph partitioner would also find for this geometry).
+
+Exchange pattern per step: ghost values of psi (once), of the PCG direction and
+the level-0 smoothing iterates (per PCG iteration), of mu (once); sums over ranks for the dot
+products and for the restricted residual of the replicated coarse AMG levels.
+
+Everything here is deterministic and computed redundantly by every rank from the global mesh, so
+send and receive lists agree without any negotiation.
+"""
+
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+
+def rcb_partition(sites: np.ndarray, nparts: int) -> np.ndarray:
+    """Recursive coordinate bisection: ``part[i]`` in ``0..nparts-1``.  Splits are made along
+    the longer extent of the current piece, proportionally when ``nparts`` is not a power of 2."""
+    part = np.zeros(len(sites), dtype=np.int32)
+
+    def split(idx, first, count):
+        if count == 1:
+            part[idx] = first
+            return
+        left = count // 2
+        pts = sites[idx]
+        axis = int(np.argmax(np.ptp(pts, axis=0)))
+        # stable order: coordinate, then the other coordinate, then index -> deterministic
+        order = np.lexsort((idx, pts[:, 1 - axis], pts[:, axis]))
+        k = int(round(len(idx) * left / count))
+        split(idx[order[:k]], first, left)
+        split(idx[order[k:]], first + left, count - left)
+
+    split(np.arange(len(sites)), 0, int(nparts))
+    return part
+
+
+@dataclass
+class LocalProblem:
+    """What one rank needs: its sub-mesh in local numbering and the halo plan."""
+
+    rank: int
+    world: int
+    n_global: int
+    n_own: int
+    local_to_global: np.ndarray          # [n_loc] owned first, then ghosts grouped by owner
+    edge_local_to_global: np.ndarray     # [m_loc]
+    owned_edge_mask: np.ndarray          # [m_loc] True where this rank reports the edge
+    mesh: object                         # Mesh-like with local arrays (tdgl_amd.finite_volume)
+    fixed_sites: np.ndarray              # local ids (owned or ghost)
+    neighbors: List[int] = field(default_factory=list)
+    send_idx: Dict[int, np.ndarray] = field(default_factory=dict)   # local owned ids per neighbour
+    recv_range: Dict[int, tuple] = field(default_factory=dict)      # (start, stop) into local ids
+    boundary_positions: np.ndarray = None  # positions (in the GLOBAL boundary list) of local boundary edges
+
+    @property
+    def n_loc(self):
+        return len(self.local_to_global)
+
+    @property
+    def n_ghost(self):
+        return self.n_loc - self.n_own
+
+
+def build_local_problem(mesh, part: np.ndarray, rank: int, fixed_sites=None) -> LocalProblem:
+    """Cut ``mesh`` (global, tdgl_amd.finite_volume.Mesh) for ``rank``."""
+    from .finite_volume import EdgeMesh, Mesh
+
+    em = mesh.edge_mesh
+    n = len(mesh.sites)
+    world = int(part.max()) + 1
+    e0, e1 = em.edges[:, 0], em.edges[:, 1]
+    own_mask = part == rank
+    touch = own_mask[e0] | own_mask[e1]
+    edge_ids = np.flatnonzero(touch)
+    # owned sites in reverse Cuthill-McKee order of the owned sub-graph (gather locality)
+    owned = np.flatnonzero(own_mask)
+    both = own_mask[e0] & own_mask[e1]
+    g2o = np.full(n, -1, dtype=np.int64)
+    g2o[owned] = np.arange(len(owned))
+    sub = sp.csr_matrix(
+        (np.ones(2 * int(both.sum()), dtype=np.int8),
+         (np.concatenate([g2o[e0[both]], g2o[e1[both]]]), np.concatenate([g2o[e1[both]], g2o[e0[both]]]))),
+        shape=(len(owned), len(owned)),
+    )
+    owned = owned[np.asarray(reverse_cuthill_mckee(sub, symmetric_mode=True))]
+    # ghosts: the other endpoint of cut edges, grouped by owner, ascending global id inside a group
+    ends = np.concatenate([e0[edge_ids], e1[edge_ids]])
+    ghosts = np.unique(ends[~own_mask[ends]])
+    ghosts = ghosts[np.lexsort((ghosts, part[ghosts]))]
+    l2g = np.concatenate([owned, ghosts]).astype(np.int64)
+    g2l = np.full(n, -1, dtype=np.int64)
+    g2l[l2g] = np.arange(len(l2g))
+    n_own = len(owned)
+
+    neighbors = sorted(set(part[ghosts].tolist()))
+    recv_range, send_idx = {}, {}
+    for nb in neighbors:
+        sel = np.flatnonzero(part[ghosts] == nb)
+        recv_range[nb] = (n_own + int(sel[0]), n_own + int(sel[-1]) + 1)
+        # what `nb` needs from us = our owned sites adjacent to its owned sites, ascending global id
+        nb_mask = part == nb
+        cut = (own_mask[e0] & nb_mask[e1]) | (own_mask[e1] & nb_mask[e0])
+        mine = np.where(own_mask[e0[cut]], e0[cut], e1[cut])
+        send_idx[nb] = g2l[np.unique(mine)]
+
+    local_edges = np.column_stack([g2l[e0[edge_ids]], g2l[e1[edge_ids]]])
+    # an edge is reported by the owner of its first endpoint (cut edges exist on two ranks)
+    owned_edge = own_mask[e0[edge_ids]]
+    is_b = np.zeros(len(em.edges), dtype=bool)
+    is_b[em.boundary_edge_indices] = True
+    pos_of_edge = np.full(len(em.edges), -1, dtype=np.int64)
+    pos_of_edge[em.boundary_edge_indices] = np.arange(len(em.boundary_edge_indices))
+    local_b = np.flatnonzero(is_b[edge_ids])
+    lem = EdgeMesh(
+        em.centers[edge_ids], local_edges, local_b, em.directions[edge_ids],
+        em.edge_lengths[edge_ids], em.dual_edge_lengths[edge_ids],
+    )
+    lmesh = Mesh(mesh.sites[l2g], np.zeros((0, 3), dtype=np.int64), np.array([], dtype=np.int64),
+                 areas=mesh.areas[l2g], edge_mesh=lem)
+    fixed = np.array([], dtype=np.int64) if fixed_sites is None else np.asarray(fixed_sites, dtype=np.int64)
+    fixed_local = g2l[fixed]
+    fixed_local = fixed_local[fixed_local >= 0]
+    return LocalProblem(
+        rank=rank, world=world, n_global=n, n_own=n_own, local_to_global=l2g,
+        edge_local_to_global=edge_ids, owned_edge_mask=owned_edge, mesh=lmesh, fixed_sites=fixed_local,
+        neighbors=neighbors, send_idx=send_idx, recv_range=recv_range,
+        boundary_positions=pos_of_edge[edge_ids[local_b]],
+    )
+
+
+def local_hierarchy_level0(h, lp: LocalProblem):
+    """Slice level 0 of the GLOBAL AMG hierarchy ``h`` (built in global numbering) for one rank:
+
+    * ``A``  rows = owned sites, columns = local sites (owned + ghosts);
+    * ``P``  rows = all local sites (ghost rows too: the coarse correction of a ghost value is
+             then computed locally, saving one exchange per cycle), columns = global coarse;
+    * ``R``  = ``P[owned].T``: the restriction restricted to owned fine columns -- its product
+             with the owned residual is this rank's PARTIAL coarse right-hand side; the partials
+             are summed over ranks.
+    Coarser levels are replicated on every rank unchanged.
+    """
+    lv0 = h.levels[0]
+    l2g = lp.local_to_global
+    own = l2g[: lp.n_own]
+    g2l = np.full(lv0.A.shape[0], -1, dtype=np.int64)
+    g2l[l2g] = np.arange(len(l2g))
+    A = lv0.A.tocsr()[own]
+    A = sp.csr_matrix((A.data, g2l[A.indices], A.indptr), shape=(lp.n_own, len(l2g)))
+    assert A.indices.min() >= 0, "halo does not cover the stencil"
+    A.sort_indices()
+    P = lv0.P.tocsr()[l2g]
+    P.sort_indices()
+    R = P[: lp.n_own].T.tocsr()
+    R.sort_indices()
+    return dict(A=A, dinv=lv0.dinv[own], rho=lv0.rho, P=P, R=R)

@@ -1,0 +1,109 @@
+"""Host model of the DISTRIBUTED step (test infrastructure; NumPy + torch.distributed/gloo).
+
+It executes, with NumPy arithmetic, exactly the algorithm the HIP library runs in one-process-
+per-GPU mode on the plan produced by `tdgl_amd.partition`:
+
+* owned rows only, ghost copies refreshed by neighbour exchange where the library does it;
+* PCG with global dot products (all-reduce), level 0 of the AMG hierarchy distributed, coarser
+  levels replicated, the restricted residual summed over ranks.
+
+`tests/test_distributed_cpu.py` runs it with world_size 2 and 3 under gloo and compares against
+the single-domain oracle, which validates the partitioner, the halo send/receive lists and the
+slicing of the hierarchy -- the data the GPU path consumes.
+"""
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from tdgl_amd.amg import smoother_coefficients, vcycle_host
+
+
+def halo_exchange(lp, vec):
+    """Refresh the ghost entries of the local vector ``vec`` (float64 or complex128) in place."""
+    width = 2 if np.iscomplexobj(vec) else 1
+    flat = vec.view(np.float64).reshape(len(vec), width)
+    reqs, recv_bufs = [], {}
+    for nb in lp.neighbors:
+        a, b = lp.recv_range[nb]
+        recv_bufs[nb] = torch.empty((b - a, width), dtype=torch.float64)
+        reqs.append(dist.irecv(recv_bufs[nb], src=nb))
+    for nb in lp.neighbors:
+        reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(flat[lp.send_idx[nb]])), dst=nb))
+    for r in reqs:
+        r.wait()
+    for nb in lp.neighbors:
+        a, b = lp.recv_range[nb]
+        flat[a:b] = recv_bufs[nb].numpy()
+
+
+def allreduce_sum(x):
+    t = torch.from_numpy(np.atleast_1d(np.asarray(x, dtype=np.float64)).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy() if t.numel() > 1 else float(t.item())
+
+
+def vcycle_dist(h, loc0, lp, b_own, nu=2, smoother="chebyshev", cheb_lo=0.1):
+    """One V-cycle: level 0 distributed (`loc0` from partition.local_hierarchy_level0), levels
+    >= 1 replicated.  Exchanges happen exactly where csrc/poisson.inc places them."""
+    A, dinv, P, R = loc0["A"], loc0["dinv"], loc0["P"], loc0["R"]
+    n_own = lp.n_own
+    c1, c2 = smoother_coefficients(loc0["rho"], nu, smoother, cheb_lo)
+    x = np.zeros(lp.n_loc)
+    d = c2[0] * dinv * b_own
+    x[:n_own] = d
+    for k in range(1, nu):
+        halo_exchange(lp, x)
+        d = c1[k] * d + c2[k] * dinv * (b_own - A @ x)
+        x[:n_own] += d
+    halo_exchange(lp, x)
+    r = b_own - A @ x
+    bc = allreduce_sum(R @ r)  # partial restrictions summed over ranks
+    ec = vcycle_host(h, bc, nu, smoother, cheb_lo, lvl=1) if len(h.levels) > 1 else None
+    x += P @ ec  # ghost rows included: ghosts stay valid without an exchange
+    for k in range(nu):
+        if k > 0:
+            halo_exchange(lp, x)
+        d = c1[k] * d + c2[k] * dinv * (b_own - A @ x)
+        x[:n_own] += d
+    return x[:n_own].copy()
+
+
+def pcg_dist(h, loc0, lp, b_own, x0_loc=None, rtol=1e-10, maxiter=200):
+    """Distributed PCG for A mu = b; returns (mu_local incl. valid ghosts, iterations)."""
+    A = loc0["A"]
+    n_own, n_glob = lp.n_own, lp.n_global
+    b = b_own - allreduce_sum(b_own.sum()) / n_glob
+    x = np.zeros(lp.n_loc) if x0_loc is None else x0_loc.copy()
+    r = b - A @ x
+    bb = allreduce_sum(b @ b)
+    rr = allreduce_sum(r @ r)
+    if bb == 0:
+        return np.zeros(lp.n_loc), 0
+    p = np.zeros(lp.n_loc)
+    rz_old, it = None, 0
+    while rr > rtol * rtol * bb and it < maxiter:
+        z = vcycle_dist(h, loc0, lp, r)
+        rz = allreduce_sum(r @ z)
+        p[:n_own] = z if rz_old is None else z + (rz / rz_old) * p[:n_own]
+        halo_exchange(lp, p)
+        q = A @ p
+        alpha = rz / allreduce_sum(p[:n_own] @ q)
+        x[:n_own] += alpha * p[:n_own]
+        r -= alpha * q
+        rr = allreduce_sum(r @ r)
+        rz_old = rz
+        it += 1
+    x[:n_own] -= allreduce_sum(x[:n_own].sum()) / n_glob
+    halo_exchange(lp, x)
+    return x, it
+
+
+def gather_global(lp, local_owned_values, n_global, dtype=np.float64):
+    """Assemble a global site vector from every rank's owned values (all ranks get it)."""
+    out = np.zeros(n_global, dtype=dtype)
+    out[lp.local_to_global[: lp.n_own]] = local_owned_values
+    flat = out.view(np.float64).copy()
+    t = torch.from_numpy(flat)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy().view(dtype)

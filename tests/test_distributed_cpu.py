@@ -1,0 +1,175 @@
+"""Multi-process (gloo, CPU) tests of the domain decomposition: partitioner, halo plan, sliced AMG
+hierarchy and the distributed step algorithm, against the single-domain oracle."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from helpers import GAMMA_DEFAULT, U_DEFAULT, edge_terminal, synthetic_mesh, uniform_field_A
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+# ---------------------------------------------------------------- single-process checks
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_partition_is_balanced_and_halo_plan_is_consistent(world):
+    from tdgl_amd.partition import build_local_problem, rcb_partition
+
+    mesh = synthetic_mesh(40, 25)
+    n = len(mesh.sites)
+    part = rcb_partition(mesh.sites, world)
+    counts = np.bincount(part, minlength=world)
+    assert counts.sum() == n and counts.max() - counts.min() <= world  # balanced
+    lps = [build_local_problem(mesh, part, r) for r in range(world)]
+    owners = np.full(n, -1)
+    for lp in lps:
+        own = lp.local_to_global[: lp.n_own]
+        assert np.all(owners[own] == -1)
+        owners[own] = lp.rank
+        assert np.all(part[lp.local_to_global[lp.n_own:]] != lp.rank)  # ghosts are foreign
+    assert np.all(owners >= 0)
+    for lp in lps:  # what A sends is what B expects, in the same order
+        for nb in lp.neighbors:
+            other = lps[nb]
+            assert lp.rank in other.neighbors
+            a, b = other.recv_range[lp.rank]
+            assert np.array_equal(lp.local_to_global[lp.send_idx[nb]], other.local_to_global[a:b])
+    # every global edge is reported by exactly one rank; cut edges exist on both sides
+    seen = np.zeros(len(mesh.edge_mesh.edges), dtype=int)
+    for lp in lps:
+        seen[lp.edge_local_to_global[lp.owned_edge_mask]] += 1
+        e = lp.mesh.edge_mesh
+        assert np.array_equal(lp.local_to_global[e.edges], mesh.edge_mesh.edges[lp.edge_local_to_global])
+    assert np.all(seen == 1)
+    # cut size of a compact partition: far below the edge count
+    cut = (part[mesh.edge_mesh.edges[:, 0]] != part[mesh.edge_mesh.edges[:, 1]]).sum()
+    assert cut < 0.12 * len(mesh.edge_mesh.edges)
+
+
+# ---------------------------------------------------------------- multi-process model
+def _worker(rank, world, port, case, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _run_case(rank, world, case, out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_case(rank, world, case, out_dir):
+    import scipy.sparse.linalg as spla
+
+    from dist_model import gather_global, halo_exchange, pcg_dist
+    from oracle import FVOperators, psi_update
+    from tdgl_amd.amg import build_hierarchy
+    from tdgl_amd.hipcore import poisson_matrix
+    from tdgl_amd.partition import build_local_problem, local_hierarchy_level0, rcb_partition
+
+    mesh = synthetic_mesh(36, 24)
+    n = len(mesh.sites)
+    em = mesh.edge_mesh
+    terms = [edge_terminal(mesh, "source", -18.0), edge_terminal(mesh, "drain", 18.0)] if case == "transport" else []
+    fixed = np.concatenate([t["site_indices"] for t in terms]) if terms else np.array([], dtype=np.int64)
+    ops = FVOperators(mesh, fixed_sites=fixed, fix_psi=True)
+    ops.build_operators()
+    ops.set_link_exponents(uniform_field_A(mesh, 0.4))
+    rng = np.random.default_rng(3)
+    psi = np.exp(1j * rng.uniform(0, 2 * np.pi, n)) * rng.uniform(0.3, 1.0, n)
+    psi[fixed] = 0
+    mu = rng.normal(0, 0.3, n)
+    mu_b = np.zeros(len(em.boundary_edge_indices))
+    for t, j in zip(terms, (0.4, -0.4)):
+        mu_b[t["boundary_edge_indices"]] = j
+    dt = 0.01
+
+    # ---- single-domain oracle step -----------------------------------------------------------
+    new_psi, _ = psi_update(psi, np.abs(psi) ** 2, mu, np.ones(n), GAMMA_DEFAULT, U_DEFAULT, dt, ops.psi_laplacian)
+    js = ops.get_supercurrent(new_psi)
+    rhs = ops.divergence @ js - ops.mu_boundary_laplacian @ mu_b
+    mu_ref = ops.mu_laplacian_lu(rhs)
+    mu_ref = mu_ref - mu_ref.mean()
+
+    # ---- the same step, distributed --------------------------------------------------------------
+    part = rcb_partition(mesh.sites, world)
+    lp = build_local_problem(mesh, part, rank, fixed_sites=fixed)
+    l2g, n_own = lp.local_to_global, lp.n_own
+    own = l2g[:n_own]
+    Lpsi = ops.psi_laplacian.tocsr()[own][:, l2g]  # owned rows, local columns
+    assert abs(ops.psi_laplacian.tocsr()[own]).sum() == pytest.approx(abs(Lpsi).sum())  # halo covers the stencil
+    psi_loc = psi[l2g].copy()
+    psi_loc[n_own:] = np.nan  # ghosts must come from the exchange
+    halo_exchange(lp, psi_loc)
+    assert np.array_equal(psi_loc, psi[l2g])
+    lap_own = Lpsi @ psi_loc
+    p_own, _ = psi_update(psi[own], np.abs(psi[own]) ** 2, mu[own], np.ones(n_own), GAMMA_DEFAULT, U_DEFAULT, dt,
+                          _Fixed(lap_own))
+    new_loc = np.zeros(lp.n_loc, dtype=complex)
+    new_loc[:n_own] = p_own
+    halo_exchange(lp, new_loc)
+    # rhs from the unmasked Laplacian rows: b_i = -a_i (Im(conj(psi_i) S_i) - c_i)
+    free = FVOperators(mesh, fix_psi=False)
+    free.build_operators()
+    free.set_link_exponents(uniform_field_A(mesh, 0.4))
+    S = free.psi_laplacian.tocsr()[own][:, l2g] @ new_loc
+    cvec = (ops.mu_boundary_laplacian @ mu_b)[own]
+    b_own = -mesh.areas[own] * ((new_loc[:n_own].conj() * S).imag - cvec)
+    A_glob = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
+    h = build_hierarchy(A_glob, max_coarse=60)
+    assert len(h.levels) >= 2
+    loc0 = local_hierarchy_level0(h, lp)
+    mu_loc, iters = pcg_dist(h, loc0, lp, b_own, x0_loc=mu[l2g] - mu.mean(), rtol=1e-12)
+    assert 0 < iters < 60
+    mu_dist = gather_global(lp, mu_loc[:n_own], n)
+    psi_dist = gather_global(lp, new_loc[:n_own], n, dtype=np.complex128)
+    # ghosts of the solution are valid after the final exchange
+    assert np.allclose(mu_loc[n_own:], mu_dist[l2g[n_own:]], atol=1e-14)
+    # edge currents on the local edges, reported by the owner of the first endpoint
+    e = lp.mesh.edge_mesh
+    grad = (ops.psi_gradient.tocsr()[lp.edge_local_to_global][:, l2g]) @ new_loc
+    js_loc = (new_loc[e.edges[:, 0]].conj() * grad).imag
+    js_glob = np.zeros(len(em.edges))
+    js_glob[lp.edge_local_to_global[lp.owned_edge_mask]] = js_loc[lp.owned_edge_mask]
+    import torch
+
+    t = torch.from_numpy(js_glob)
+    import torch.distributed as dist
+
+    dist.all_reduce(t)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, f"{case}_{world}.npz"), psi_err=np.abs(psi_dist - new_psi).max(),
+                 mu_err=np.abs(mu_dist - mu_ref).max() / np.abs(mu_ref).max(),
+                 js_err=np.abs(t.numpy() - js).max(), iters=iters)
+
+
+class _Fixed:
+    """Stands in for `psi_laplacian` in oracle.psi_update: returns a precomputed product."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __matmul__(self, other):
+        return self.value
+
+
+@pytest.mark.parametrize("world,case", [(2, "field"), (2, "transport"), (3, "transport")])
+def test_distributed_step_matches_single_domain_oracle(world, case, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    res = np.load(os.path.join(tmp_path, f"{case}_{world}.npz"))
+    assert res["psi_err"] < 1e-14  # pointwise update of identical inputs
+    assert res["js_err"] < 1e-13
+    assert res["mu_err"] < 1e-9  # PCG to 1e-12 vs LU, modulo the constant
