@@ -59,6 +59,9 @@ typedef struct {
                                              (e.g. reverse Cuthill-McKee); NULL = identity */
     double u;                             /* Layer.u      (tdgl/device/layer.py:30)    */
     double gamma;                         /* Layer.gamma  (tdgl/device/layer.py:31)    */
+    int64_t n_owned;                      /* one-process-per-GPU mode: sites [0, n_owned) are
+                                             owned by this rank, [n_owned, n_sites) are ghost
+                                             copies (site_perm must then be NULL); 0 = all    */
 } tdgl_mesh_desc;
 
 /* One level of the algebraic-multigrid hierarchy that preconditions the mu solve
@@ -72,6 +75,8 @@ typedef struct {
     double rho;           /* estimate of the spectral radius of D^-1 A                 */
     const int32_t *P_indptr;  const int32_t *P_indices;  const double *P_data; /* n x n_coarse */
     const int32_t *R_indptr;  const int32_t *R_indices;  const double *R_data; /* n_coarse x n */
+    int64_t n_cols;       /* level 0 in distributed mode: columns of A / rows of P = owned +
+                             ghost sites (A is n x n_cols, P is n_cols x n_coarse); 0 = n    */
 } tdgl_amg_level;
 
 /* Adaptive time-step controller = SolverOptions fields read by the step
@@ -117,6 +122,37 @@ int tdgl_synchronize(tdgl_ctx *ctx);
 int tdgl_poisson_set_hierarchy(tdgl_ctx *ctx, const tdgl_amg_level *levels, int32_t n_levels,
                                const double *coarse_pinv);
 int tdgl_set_poisson_options(tdgl_ctx *ctx, const tdgl_poisson_options *opts);
+
+/* ------------------------------------------------------------------ one process per GPU
+ * The reference is single-process.  Here the mesh is cut into `world` pieces (host layer:
+ * tdgl_amd/partition.py); each rank creates its context from its sub-mesh (owned sites first,
+ * ghosts after, tdgl_mesh_desc.n_owned) and registers which owned sites every neighbour needs
+ * and where each neighbour's values land among the ghosts.  Level 0 of the AMG hierarchy is
+ * sliced per rank, coarser levels are replicated.  Per step the library exchanges ghost values
+ * of psi, of the PCG direction / smoothing iterates and of mu, and sums dot products and the
+ * restricted residual over ranks. */
+typedef struct {
+    int32_t rank, world;
+    int64_t n_global;                /* total number of sites                             */
+    int32_t n_neighbors;
+    const int32_t *neighbor_ranks;   /* [n_neighbors]                                     */
+    const int32_t *send_ptr;         /* [n_neighbors + 1] offsets into send_idx           */
+    const int32_t *send_idx;         /* owned local site ids to send, grouped by neighbour */
+    const int32_t *recv_ptr;         /* [n_neighbors + 1] offsets into the ghost range:
+                                        neighbour k fills sites n_owned + recv_ptr[k] ...  */
+} tdgl_halo_plan;
+int tdgl_set_halo_plan(tdgl_ctx *ctx, const tdgl_halo_plan *plan);
+/* RCCL transport (xGMI): rank 0 makes the 128-byte id, the host layer broadcasts it, every rank
+ * calls tdgl_comm_init_rccl.  Collectives run on the context's stream. */
+int tdgl_comm_unique_id(char *out128);
+int tdgl_comm_init_rccl(tdgl_ctx *ctx, const char *id128);
+/* Host-callback transport (tests: lets two ranks share one GPU, which RCCL refuses).  Buffers are
+ * host arrays of doubles; offsets are in doubles; return 0 on success.
+ * allreduce op: 0 = sum, 1 = max (in place). */
+typedef int (*tdgl_halo_fn)(void *user, const double *send, const int64_t *send_off, double *recv,
+                            const int64_t *recv_off, int32_t n_neighbors, const int32_t *neighbor_ranks);
+typedef int (*tdgl_allreduce_fn)(void *user, double *buf, int64_t count, int32_t op);
+int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn allreduce, void *user);
 
 /* ------------------------------------------------------------------ inputs */
 /* MeshOperators.set_link_exponents (operators.py:310-383): A[n_edges, 2], dimensionless.

@@ -113,6 +113,9 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto *lv : ctx->levels) delete lv;
+    if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    if (ctx->h_sendbuf) (void)hipHostFree(ctx->h_sendbuf);
+    if (ctx->h_recvbuf) (void)hipHostFree(ctx->h_recvbuf);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->h_probe_out) (void)hipHostFree(ctx->h_probe_out);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -140,6 +143,10 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     ctx->nb = nb;
     ctx->n_pad = round_up(n, WAVE);
     ctx->m_pad = round_up(std::max<int64_t>(m, 1), WAVE);
+    ctx->n_own = (d->n_owned > 0) ? d->n_owned : n;
+    ctx->n_global = n;
+    if (ctx->n_own > n) TDGL_FAIL(ctx, TDGL_ERR_ARG, "n_owned exceeds n_sites");
+    if (ctx->n_own < n && d->site_perm) TDGL_FAIL(ctx, TDGL_ERR_ARG, "site_perm must be NULL when n_owned < n_sites");
     ctx->u = d->u;
     ctx->gamma = d->gamma;
     ctx->fix_psi = d->fix_psi != 0;
@@ -213,8 +220,10 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
             code[k] = row[k - b].second;
         }
     }
+    // rows exist for owned sites only; ghost sites appear as columns
+    const int64_t n_rows = ctx->n_own;
     std::vector<int64_t> slot;
-    TDGL_TRY(build_sell_pattern(ctx, n, indptr.data(), nbr.data(), ctx->lap_pat, &slot));
+    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr.data(), nbr.data(), ctx->lap_pat, &slot));
     const int64_t n_slots = ctx->lap_pat.n_slots;
     std::vector<int32_t> slot_edge(n_slots, -1);
     std::vector<double> slot_w(n_slots, 0.0), diag(ctx->n_pad, 0.0), area(ctx->n_pad, 0.0);
@@ -222,6 +231,7 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
         const double a = d->areas[ctx->perm[i]];
         if (!(a > 0.0)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "site %d has non-positive area", ctx->perm[i]);
         area[i] = a;
+        if (i >= n_rows) continue;
         double dsum = 0.0;
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
             const double wk = w[code[k] >> 1];
@@ -378,8 +388,8 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
 
 static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
                               double dt, double2 *psi_new, double *abs_sq) {
-    const int grid = std::min<int64_t>(grid_for(ctx->n), 2048);
-    hipLaunchKernelGGL(k_psi_update, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->n, psi, mu,
+    const int grid = std::min<int64_t>(grid_for(ctx->n_own), 2048);
+    hipLaunchKernelGGL(k_psi_update, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->n_own, psi, mu,
                        ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p);
 }
 
@@ -397,6 +407,7 @@ static void launch_edge_currents(tdgl_ctx *ctx, const double2 *psi, const double
                            ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
 }
 
+#include "comm.inc"
 #include "poisson.inc"
 #include "run.inc"
 

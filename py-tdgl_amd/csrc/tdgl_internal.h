@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -114,7 +115,21 @@ struct tdgl_ctx {
     std::string err;
 
     int64_t n = 0, m = 0, nb = 0, n_pad = 0, m_pad = 0;
+    int64_t n_own = 0;     // rows this rank computes (sites [n_own, n) are ghost copies)
+    int64_t n_global = 0;  // sites over all ranks
     double u = 5.79, gamma = 10.0;
+
+    // ---- one-process-per-GPU mode (comm.inc) -----------------------------------------
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    tdgl_halo_fn cb_halo = nullptr;
+    tdgl_allreduce_fn cb_allreduce = nullptr;
+    void *cb_user = nullptr;
+    std::vector<int32_t> nbr_ranks, send_ptr, recv_ptr;
+    tdgl::DevBuf<int32_t> d_send_idx;
+    tdgl::DevBuf<double> d_sendbuf, d_gstat;
+    double *h_sendbuf = nullptr, *h_recvbuf = nullptr;  // pinned (callback transport)
+    int64_t h_buf_doubles = 0;
     bool fix_psi = true;
 
     // permutations (host)

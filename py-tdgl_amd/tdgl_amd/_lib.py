@@ -41,6 +41,7 @@ class MeshDesc(C.Structure):
         ("site_perm", c_i32p),
         ("u", C.c_double),
         ("gamma", C.c_double),
+        ("n_owned", C.c_int64),
     ]
 
 
@@ -59,7 +60,26 @@ class AmgLevel(C.Structure):
         ("R_indptr", c_i32p),
         ("R_indices", c_i32p),
         ("R_data", c_f64p),
+        ("n_cols", C.c_int64),
     ]
+
+
+class HaloPlan(C.Structure):
+    _fields_ = [
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("n_global", C.c_int64),
+        ("n_neighbors", C.c_int32),
+        ("neighbor_ranks", c_i32p),
+        ("send_ptr", c_i32p),
+        ("send_idx", c_i32p),
+        ("recv_ptr", c_i32p),
+    ]
+
+
+c_i64p = C.POINTER(C.c_int64)
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_f64p, c_i64p, c_f64p, c_i64p, C.c_int32, c_i32p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_f64p, C.c_int64, C.c_int32)
 
 
 class Controller(C.Structure):
@@ -97,6 +117,10 @@ SIGNATURES = {
     "tdgl_synchronize": (C.c_int, [_CTX]),
     "tdgl_poisson_set_hierarchy": (C.c_int, [_CTX, C.POINTER(AmgLevel), C.c_int32, c_f64p]),
     "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
+    "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
+    "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),
+    "tdgl_comm_init_callbacks": (C.c_int, [_CTX, HALO_FN, ALLREDUCE_FN, C.c_void_p]),
     "tdgl_set_link_exponents": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_epsilon": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_mu_boundary": (C.c_int, [_CTX, c_f64p]),

@@ -112,15 +112,23 @@ def estimate_rho_DinvA(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 20, seed
     """Largest eigenvalue of D^-1 A by power iteration on the symmetrised operator."""
     n = A.shape[0]
     rng = np.random.default_rng(seed)
-    x = rng.standard_normal(n)
     sq = np.sqrt(dinv)
-    lam = 1.0
-    for _ in range(iters):
-        x /= np.linalg.norm(x)
-        y = sq * (A @ (sq * x))
-        lam = float(x @ y)
-        x = y
-    return lam
+    # Gershgorin: never exceeded, and tight (= 2) for the fine-level M-matrix
+    gersh = float((abs(A) @ np.ones(n) * dinv).max())
+    if n < 50:
+        S = (A.toarray() * sq[:, None]) * sq[None, :]
+        return min(gersh, float(np.linalg.eigvalsh(S)[-1]))
+    # The Chebyshev smoother diverges on eigenvalues above its upper bound, so a plain power
+    # iteration (which converges from below, slowly) is not safe: use Lanczos.
+    import scipy.sparse.linalg as spla
+
+    op = spla.LinearOperator((n, n), matvec=lambda v: sq * (A @ (sq * v)), dtype=float)
+    try:
+        lam = float(spla.eigsh(op, k=1, which="LA", tol=1e-3, maxiter=200 * 1,
+                               v0=rng.standard_normal(n), return_eigenvectors=False)[0])
+    except spla.ArpackNoConvergence as exc:  # keep whatever ARPACK reached, else the bound
+        lam = float(exc.eigenvalues[0]) if len(exc.eigenvalues) else gersh
+    return min(gersh, lam)
 
 
 @dataclass

@@ -43,7 +43,9 @@ class TDGLContext:
     """Owns one ``tdgl_ctx`` (device buffers + stream) for a mesh."""
 
     def __init__(self, mesh, fixed_sites=None, fix_psi=True, u=5.79, gamma=10.0, device_id=0,
-                 reorder="rcm"):
+                 reorder="rcm", n_owned=0):
+        """``n_owned`` > 0: one-process-per-GPU mode, ``mesh`` is a rank's sub-mesh from
+        `partition.build_local_problem` (owned sites first, then ghosts; no reordering)."""
         _lib.require_gpu()
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
@@ -53,6 +55,9 @@ class TDGLContext:
         self.n_boundary = len(em.boundary_edge_indices)
         self.n_probe = 0
         edges = i32(em.edges)
+        self.n_owned = int(n_owned) if n_owned else self.n
+        if n_owned:
+            reorder = None
         if reorder == "rcm":
             perm = rcm_permutation(em.edges, self.n)
         elif reorder is None or reorder == "none":
@@ -75,7 +80,8 @@ class TDGLContext:
             dual_edge_lengths=p_f64(k["dl"]), directions=p_f64(k["dirs"]),
             boundary_edge_indices=p_i32(k["bidx"]),
             fixed_sites=p_i32(fixed) if len(fixed) else None, n_fixed=len(fixed),
-            fix_psi=int(bool(fix_psi)), site_perm=p_i32(perm), u=float(u), gamma=float(gamma),
+            fix_psi=int(bool(fix_psi)), site_perm=None if n_owned else p_i32(perm), u=float(u),
+            gamma=float(gamma), n_owned=int(n_owned),
         )
         _lib.check(self._lib.tdgl_create(C.byref(self._ctx), C.byref(desc), int(device_id)))
         self.hierarchy = None
@@ -112,7 +118,77 @@ class TDGLContext:
                                  smoother, cheb_lo, extrapolate)
         return h
 
-    def set_hierarchy(self, h: Hierarchy):
+    # -- one process per GPU -------------------------------------------------------------
+    def set_halo_plan(self, lp):
+        """Register the halo plan of `partition.LocalProblem` ``lp``."""
+        nbrs = i32(lp.neighbors)
+        send_ptr = i32(np.concatenate([[0], np.cumsum([len(lp.send_idx[nb]) for nb in lp.neighbors])]))
+        send_idx = i32(np.concatenate([lp.send_idx[nb] for nb in lp.neighbors]) if lp.neighbors else [])
+        recv_ptr = i32([0] + [lp.recv_range[nb][1] - lp.n_own for nb in lp.neighbors])
+        for k, nb in enumerate(lp.neighbors):  # ghost ranges are contiguous and in neighbour order
+            assert lp.recv_range[nb][0] - lp.n_own == recv_ptr[k]
+        self._halo_keep = (nbrs, send_ptr, send_idx, recv_ptr)
+        plan = _lib.HaloPlan(
+            rank=lp.rank, world=lp.world, n_global=lp.n_global, n_neighbors=len(nbrs),
+            neighbor_ranks=p_i32(nbrs) if len(nbrs) else None, send_ptr=p_i32(send_ptr),
+            send_idx=p_i32(send_idx) if len(send_idx) else None, recv_ptr=p_i32(recv_ptr),
+        )
+        self._chk(self._lib.tdgl_set_halo_plan(self._ctx, C.byref(plan)))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().tdgl_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rccl(self, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._chk(self._lib.tdgl_comm_init_rccl(self._ctx, C.c_char_p(unique_id)))
+
+    def comm_init_callbacks(self, halo, allreduce):
+        """``halo(send, send_off, recv, recv_off, ranks)`` and ``allreduce(buf, op)`` operate on
+        NumPy views of the library's pinned host buffers (test transport)."""
+
+        def _halo(user, send, send_off, recv, recv_off, nn, ranks):
+            try:
+                so = np.ctypeslib.as_array(send_off, shape=(nn + 1,))
+                ro = np.ctypeslib.as_array(recv_off, shape=(nn + 1,))
+                rk = np.ctypeslib.as_array(ranks, shape=(nn,))
+                halo(np.ctypeslib.as_array(send, shape=(int(so[-1]),)), so,
+                     np.ctypeslib.as_array(recv, shape=(int(ro[-1]),)), ro, rk)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _allreduce(user, buf, count, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(count),)), int(op))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._cb_keep = (_lib.HALO_FN(_halo), _lib.ALLREDUCE_FN(_allreduce))
+        self._chk(self._lib.tdgl_comm_init_callbacks(self._ctx, self._cb_keep[0], self._cb_keep[1], None))
+
+    def set_hierarchy_distributed(self, h: Hierarchy, lp):
+        """Upload the GLOBAL hierarchy ``h`` with level 0 sliced for this rank
+        (`partition.local_hierarchy_level0`) and the coarser levels replicated."""
+        from .amg import Level
+        from .partition import local_hierarchy_level0
+
+        loc = local_hierarchy_level0(h, lp)
+        lv0 = Level(A=loc["A"], dinv=loc["dinv"], rho=loc["rho"], P=loc["P"], R=loc["R"])
+        hh = Hierarchy(levels=[lv0] + list(h.levels[1:]), coarse_pinv=h.coarse_pinv)
+        self.set_hierarchy(hh, n_cols0=lp.n_loc)
+        self.hierarchy = h
+
+    def set_hierarchy(self, h: Hierarchy, n_cols0: int = 0):
         levels = (_lib.AmgLevel * len(h.levels))()
         keep = []
         for idx, lv in enumerate(h.levels):
@@ -122,6 +198,7 @@ class TDGLContext:
             )
             L = levels[idx]
             L.n = A.shape[0]
+            L.n_cols = n_cols0 if idx == 0 else 0
             L.A_indptr, L.A_indices, L.A_data = p_i32(arrs["Ap"]), p_i32(arrs["Ai"]), p_f64(arrs["Ad"])
             L.dinv = p_f64(arrs["dinv"])
             L.rho = float(lv.rho)

@@ -1,0 +1,119 @@
+"""GPU tests of the one-process-per-GPU path.
+
+A test box has ONE MI355X and RCCL refuses two ranks on one device, so the multi-rank tests use
+the library's host-callback transport (ghost values and all-reduces staged through pinned host
+buffers and torch.distributed/gloo): every kernel, the pack/unpack, the sliced hierarchy and the
+step logic are exactly those of a multi-GPU run; only the three RCCL calls are swapped.  The RCCL
+transport itself is exercised with world_size 1 (communicator creation, all-reduce, the
+no-neighbour halo).
+"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = 60
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem():
+    for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import edge_terminal, synthetic_mesh, uniform_field_A
+    from tdgl_amd import SolverOptions
+
+    mesh = synthetic_mesh(60, 15)
+    terms = [edge_terminal(mesh, "source", -30.0), edge_terminal(mesh, "drain", 30.0)]
+    A = uniform_field_A(mesh, 0.05)
+    em = mesh.edge_mesh
+    mu_b = np.zeros(len(em.boundary_edge_indices))
+    for t, sign in zip(terms, (1.0, -1.0)):
+        mu_b[t["boundary_edge_indices"]] = sign * 6.0 / t["length"]
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=1000, pcg_rtol=1e-11)
+    probes = [mesh.closest_site((-15, 0)), mesh.closest_site((15, 0))]
+    fixed = np.concatenate([t["site_indices"] for t in terms])
+    psi0 = np.ones(len(mesh.sites), dtype=complex)
+    psi0[fixed] = 0
+    return mesh, terms, A, mu_b, opts, probes, psi0
+
+
+def _worker(rank, world, port, transport, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem()
+    from tdgl_amd import _lib  # noqa: F401  (load libtdgl_hip and its ROCm runtime before torch)
+
+    _lib.load()
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdgl_amd.distributed import DistributedTDGL
+
+        run = DistributedTDGL(mesh, opts, A, 1.0, rank=rank, world=world, terminal_info=terms, mu_boundary=mu_b,
+                              probe_points=probes, transport=transport, device_id=0)
+        run.set_state(psi0, np.zeros(len(mesh.sites)))
+        run.begin_stage()
+        res = run.run(N_STEPS)
+        fields = run.gather_state()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"dist_{transport}_{world}.npz"), dt=res["dt"], mu_probe=res["mu"],
+                     theta_probe=res["theta"], iters=res["pcg_iters"], **fields)
+        run.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_gpu_reference():
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem()
+    from tdgl_amd import TDGLSolver
+
+    cur = {"source": 6.0, "drain": -6.0}
+    solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0, terminal_info=terms, current_func=cur, probe_points=probes)
+    assert np.allclose(solver.mu_boundary, 0)  # set on the first step
+    solver.update_mu_boundary(0.0)
+    assert np.allclose(solver.mu_boundary, mu_b)
+    ctx = solver.ctx
+    ctx.set_state(psi0, np.zeros(len(mesh.sites)))
+    ctx.begin_stage()
+    res = ctx.run(N_STEPS)
+    return mesh, res, ctx.get_state()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_run_matches_single_gpu(world, tmp_path):
+    mesh, ref_res, ref = _single_gpu_reference()
+    mp.spawn(_worker, args=(world, _free_port(), "gloo", str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"dist_gloo_{world}.npz"))
+    # same algorithm, same tolerances; only the summation order of the dot products differs
+    assert len(got["dt"]) == N_STEPS
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-9
+    assert np.abs(got["mu"] - ref["mu"]).max() < 1e-9 * max(1.0, np.abs(ref["mu"]).max())
+    assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-9
+    assert np.abs(got["normal_current"] - ref["normal_current"]).max() < 1e-9
+    assert np.abs((got["mu_probe"][:, 0] - got["mu_probe"][:, 1]) - (ref_res["mu"][:, 0] - ref_res["mu"][:, 1])).max() < 1e-9
+    # the decomposition must not change the iteration count materially
+    assert abs(got["iters"].mean() - ref_res["pcg_iters"].mean()) < 2.0
+
+
+def test_rccl_transport_world_size_one(tmp_path):
+    mesh, ref_res, ref = _single_gpu_reference()
+    mp.spawn(_worker, args=(1, _free_port(), "rccl", str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(tmp_path, "dist_rccl_1.npz"))
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-12 * ref_res["dt"].max()
+    assert np.abs(got["mu"] - ref["mu"]).max() < 1e-10
+    assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-10
