@@ -16,11 +16,33 @@ all-reduces run inside `tdgl_run` over RCCL on the context's stream (transport "
 suite so that several ranks can share one GPU.
 """
 
+import contextlib
+import ctypes
+import os
+import sys
+
 import numpy as np
 
 from .amg import build_hierarchy
 from .hipcore import TDGLContext, poisson_matrix
 from .partition import build_local_problem, rcb_partition
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner through C stdio on stdout when a communicator is created;
+    programs whose stdout is machine-read (bench.py prints one JSON line) route it to stderr."""
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class DistributedTDGL:
@@ -53,7 +75,8 @@ class DistributedTDGL:
             if transport == "rccl":
                 ident = [ctx.comm_unique_id() if self.rank == 0 else None]
                 dist.broadcast_object_list(ident, src=0)
-                ctx.comm_init_rccl(ident[0])
+                with stdout_to_stderr():
+                    ctx.comm_init_rccl(ident[0])
             elif transport == "gloo":
                 ctx.comm_init_callbacks(self._halo_cb, self._allreduce_cb)
             else:
