@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--check-every", type=int, default=0, help="0 = auto (predicted)")
     ap.add_argument("--smoother", default="chebyshev", choices=["chebyshev", "jacobi"])
-    ap.add_argument("--nu", type=int, default=2)
+    ap.add_argument("--nu", type=int, default=2, help="smoother degree on the coarse levels")
+    ap.add_argument("--nu-fine", type=int, default=1, help="smoother degree on level 0")
     ap.add_argument("--no-extrapolate", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -180,7 +181,7 @@ def main():
         log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
     ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                             edge_currents_every_step=True, smoother=args.smoother,
-                            extrapolate=not args.no_extrapolate)
+                            extrapolate=not args.no_extrapolate, nu_fine=args.nu_fine)
     h = ctx.hierarchy
     log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")
     ctx.begin_stage()
@@ -263,7 +264,7 @@ def main():
         data="synthetic",
         config=dict(
             workload=f"{desc}, uniform field b=B/Bc2={B_FIELD}, adaptive dt (dt_init 1e-4, dt_max 0.1), "
-                     f"PCG rtol {args.rtol:g} ({args.smoother} degree-{args.nu} AMG smoother), J_s/J_n formed every step",
+                     f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below), J_s/J_n formed every step",
             sites=n, edges=m, amg_levels=h.sizes,
             parallelism="single" if world == 1 else
             f"domain decomposition (RCB, {world} ranks, ~{n // world} sites each), RCCL halo exchange + all-reduce",

@@ -376,12 +376,12 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
     sell_grid(ctx->lap_pat.n_slices, &per_xcd, &grid);
     if (rhs)
         hipLaunchKernelGGL(k_psi_laplacian<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
-                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
+                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
                            ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
                            ctx->cvec.p, ctx->bvec.p);
     else
         hipLaunchKernelGGL(k_psi_laplacian<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
-                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
+                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
                            ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
                            ctx->cvec.p, ctx->bvec.p);
 }

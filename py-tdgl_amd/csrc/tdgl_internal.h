@@ -173,7 +173,7 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
     tdgl::DevBuf<double> mu_prev;         // mu^{n-1} for the extrapolated initial guess
     double prev_dt = 0.0;                 // dt of the step that produced mu (0: no history)
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 1};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 1, 1};
     int32_t last_pcg_iters = 0;
     double last_relres = 0.0;
 

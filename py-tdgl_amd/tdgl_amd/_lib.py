@@ -103,6 +103,7 @@ class PoissonOptions(C.Structure):
         ("smoother", C.c_int32),
         ("cheb_lo", C.c_double),
         ("extrapolate", C.c_int32),
+        ("nu_fine", C.c_int32),
     ]
 
 

@@ -230,11 +230,16 @@ def smoother_coefficients(rho, nu=2, smoother="chebyshev", cheb_lo=0.1):
 
 
 def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 2, smoother: str = "chebyshev",
-                cheb_lo: float = 0.1, lvl: int = 0) -> np.ndarray:
+                cheb_lo: float = 0.1, lvl: int = 0, nu_fine: int = 0) -> np.ndarray:
+    """``nu_fine`` > 0 overrides the smoother degree on level 0 (the library's default is
+    degree 1 on level 0, degree 2 below)."""
     level = h.levels[lvl]
     if lvl == len(h.levels) - 1:
         return h.coarse_pinv @ b
     A, dinv = level.A, level.dinv
+    nu_all = nu
+    if lvl == 0 and nu_fine > 0:
+        nu = nu_fine
     c1, c2 = smoother_coefficients(level.rho, nu, smoother, cheb_lo)
     d = c2[0] * dinv * b
     x = d.copy()
@@ -242,7 +247,7 @@ def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 2, smoother: str = "cheby
         d = c1[k] * d + c2[k] * dinv * (b - A @ x)
         x = x + d
     r = b - A @ x
-    xc = vcycle_host(h, level.R @ r, nu, smoother, cheb_lo, lvl + 1)
+    xc = vcycle_host(h, level.R @ r, nu_all, smoother, cheb_lo, lvl + 1)
     x = x + level.P @ xc
     for k in range(nu):
         d = c1[k] * d + c2[k] * dinv * (b - A @ x)
@@ -250,7 +255,7 @@ def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 2, smoother: str = "cheby
     return x
 
 
-def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=2, smoother="chebyshev"):
+def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=2, smoother="chebyshev", nu_fine=1):
     """Preconditioned CG on the semi-definite system (b is projected onto range(A))."""
     n = len(b)
     b = b - b.mean()
@@ -259,7 +264,7 @@ def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=2, smoothe
     bnorm = np.linalg.norm(b)
     if bnorm == 0:
         return x, 0, 0.0
-    z = vcycle_host(h, r, nu, smoother)
+    z = vcycle_host(h, r, nu, smoother, nu_fine=nu_fine)
     p = z.copy()
     rz = r @ z
     res = np.linalg.norm(r) / bnorm
@@ -273,7 +278,7 @@ def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=2, smoothe
         it += 1
         if res <= rtol:
             break
-        z = vcycle_host(h, r, nu, smoother)
+        z = vcycle_host(h, r, nu, smoother, nu_fine=nu_fine)
         rz_new = r @ z
         p = z + (rz_new / rz) * p
         rz = rz_new

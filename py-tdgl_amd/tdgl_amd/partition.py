@@ -164,4 +164,5 @@ def local_hierarchy_level0(h, lp: LocalProblem):
     P.sort_indices()
     R = P[: lp.n_own].T.tocsr()
     R.sort_indices()
-    return dict(A=A, dinv=lv0.dinv[own], rho=lv0.rho, P=P, R=R)
+    # dinv for ALL local sites: the fused level-0 residual gathers dinv * r at ghost columns
+    return dict(A=A, dinv=lv0.dinv[l2g], rho=lv0.rho, P=P, R=R)

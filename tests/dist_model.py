@@ -43,11 +43,23 @@ def allreduce_sum(x):
     return t.numpy() if t.numel() > 1 else float(t.item())
 
 
-def vcycle_dist(h, loc0, lp, b_own, nu=2, smoother="chebyshev", cheb_lo=0.1):
+def vcycle_dist(h, loc0, lp, b_own, nu=2, smoother="chebyshev", cheb_lo=0.1, nu_fine=1):
     """One V-cycle: level 0 distributed (`loc0` from partition.local_hierarchy_level0), levels
     >= 1 replicated.  Exchanges happen exactly where csrc/poisson.inc places them."""
-    A, dinv, P, R = loc0["A"], loc0["dinv"], loc0["P"], loc0["R"]
+    A, dinv_loc, P, R = loc0["A"], loc0["dinv"], loc0["P"], loc0["R"]
     n_own = lp.n_own
+    dinv = dinv_loc[:n_own]
+    if nu_fine == 1:
+        # degree-1 smoothing on level 0: ONE exchange (ghosts of the right-hand side) per cycle
+        _, c2 = smoother_coefficients(loc0["rho"], 1, smoother, cheb_lo)
+        bl = np.zeros(lp.n_loc)
+        bl[:n_own] = b_own
+        halo_exchange(lp, bl)
+        r = b_own - c2[0] * (A @ (dinv_loc * bl))
+        bc = allreduce_sum(R @ r)
+        ec = vcycle_host(h, bc, nu, smoother, cheb_lo, lvl=1)
+        x = c2[0] * dinv_loc * bl + P @ ec  # valid on ghost rows too
+        return x[:n_own] + c2[0] * dinv * (b_own - A @ x)
     c1, c2 = smoother_coefficients(loc0["rho"], nu, smoother, cheb_lo)
     x = np.zeros(lp.n_loc)
     d = c2[0] * dinv * b_own

@@ -134,12 +134,12 @@ def test_vcycle_matches_host_restatement(small_ctx):
     ctx, mesh, g = small_ctx
     r = np.random.default_rng(2).normal(size=ctx.n)
     r -= r.mean()
-    for smoother, nu in (("chebyshev", 2), ("jacobi", 1), ("chebyshev", 3)):
-        ctx.set_poisson_options(rtol=1e-12, nu=nu, smoother=smoother)
+    for smoother, nu, nu_fine in (("chebyshev", 2, 1), ("chebyshev", 2, 2), ("jacobi", 1, 1), ("chebyshev", 3, 2)):
+        ctx.set_poisson_options(rtol=1e-12, nu=nu, smoother=smoother, nu_fine=nu_fine)
         want = np.empty(ctx.n)
-        want[ctx.perm] = vcycle_host(ctx.hierarchy, r[ctx.perm], nu=nu, smoother=smoother)
+        want[ctx.perm] = vcycle_host(ctx.hierarchy, r[ctx.perm], nu=nu, smoother=smoother, nu_fine=nu_fine)
         got = ctx.vcycle(r)
-        assert max_abs(got, want) < 1e-12 * np.abs(want).max(), (smoother, nu)
+        assert max_abs(got, want) < 1e-12 * np.abs(want).max(), (smoother, nu, nu_fine)
     ctx.set_poisson_options(rtol=1e-12)
 
 
