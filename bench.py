@@ -34,6 +34,8 @@ WORKLOADS = {
     "250k": (465.0, "square film 465 xi, 250,510 sites"),
     "1M": (930.0, "square film 930 xi, 1,000,431 sites"),
     "4M": (1860.0, "square film 1860 xi, ~4.0M sites"),
+    # BASELINE config 4: strip with two current terminals (short edges), I = 0.2 * Ly, zero field
+    "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 500,955 sites, two current terminals, I = 0.2 Ly"),
 }
 B_FIELD = 0.1  # B / Bc2
 
@@ -63,7 +65,7 @@ def algorithmic_bytes(n, m):
     }
 
 
-def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40):
+def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, terms=(), currents=None):
     """Time the oracle (NumPy/SciPy port of the reference step: SuperLU + sparse matvecs) on
     this host, starting from the GPU run's post-warm-up state.  Setup (operator build, LU
     factorisation) is excluded, like the GPU path's setup."""
@@ -71,7 +73,8 @@ def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40):
 
     o = SimpleNamespace(skip_time=0.0, terminal_psi=0.0, **opt_kw)
     t0 = time.perf_counter()
-    solver = OracleSolver(mesh, A, 1.0, 5.79, 10.0, o)
+    solver = OracleSolver(mesh, A, 1.0, 5.79, 10.0, o, terminals=terms,
+                          current_func=None if currents is None else (lambda t: currents))
     setup_s = time.perf_counter() - t0
     solver.tentative_dt = state["tentative_dt"]
     psi, mu = state["psi"].copy(), state["mu"].copy()
@@ -143,12 +146,28 @@ def main():
 
     side, desc = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    pts = hex_jitter_points(side, side)
+    strip = isinstance(side, tuple)
+    pts = hex_jitter_points(*side) if strip else hex_jitter_points(side, side)
     tri = triangulate(pts)
     mesh = Mesh.from_triangulation(pts, tri)
     n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
     log(f"rank {rank}: mesh {n} sites / {m} edges in {time.perf_counter() - t0:.1f} s")
-    A = uniform_A(mesh, B_FIELD)
+    A = uniform_A(mesh, 0.0 if strip else B_FIELD)
+    terms, currents = (), None
+    if strip:
+        em_ = mesh.edge_mesh
+        bidx = em_.boundary_edge_indices
+
+        def terminal(name, x0):
+            pos = np.flatnonzero(np.isclose(em_.centers[bidx, 0], x0))
+            return dict(name=name, boundary_edge_indices=pos, edge_indices=bidx[pos],
+                        length=em_.edge_lengths[bidx][pos].sum(),
+                        site_indices=np.intersect1d(np.flatnonzero(np.isclose(mesh.sites[:, 0], x0)), mesh.boundary_indices))
+
+        terms = [terminal("source", -side[0] / 2), terminal("drain", side[0] / 2)]
+        currents = {"source": 0.2 * side[1], "drain": -0.2 * side[1]}
+        if world > 1:
+            raise SystemExit("the strip workload is single-GPU in bench.py")
     opt_kw = dict(solve_time=1e12, dt_init=1e-4, dt_max=0.1, adaptive=True, adaptive_window=10,
                   max_solve_retries=10, adaptive_time_step_multiplier=0.25, save_every=10**9)
     opts = SolverOptions(**opt_kw, pcg_rtol=args.rtol, edge_currents_every_step=True, device_id=local_rank)
@@ -165,7 +184,9 @@ def main():
         with stdout_to_stderr():
             dist_mod.init_process_group("gloo", rank=0, world_size=1)
     if not use_dd:
-        solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0)
+        solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0, terminal_info=terms, current_func=currents)
+        solver.update_mu_boundary(0.0)
+        psi_init = solver.psi_init
         ctx = solver.ctx
         n_loc, m_loc = n, m
         ctx.set_state(psi_init, mu_init)
@@ -263,7 +284,7 @@ def main():
         dtype="f64",
         data="synthetic",
         config=dict(
-            workload=f"{desc}, uniform field b=B/Bc2={B_FIELD}, adaptive dt (dt_init 1e-4, dt_max 0.1), "
+            workload=f"{desc}, " + ("" if strip else f"uniform field b=B/Bc2={B_FIELD}, ") + f"adaptive dt (dt_init 1e-4, dt_max 0.1), "
                      f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below), J_s/J_n formed every step",
             sites=n, edges=m, amg_levels=h.sizes,
             parallelism="single" if world == 1 else
@@ -276,7 +297,8 @@ def main():
     )
     if start_state is not None:
         log("timing the CPU oracle (LU factorisation first; this takes a while at 1M sites)")
-        out["cpu_baseline"] = cpu_baseline(mesh, A, start_state, opt_kw, target_seconds=args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(mesh, A, start_state, opt_kw, target_seconds=args.cpu_seconds,
+                                           terms=terms, currents=currents)
         out["speedup_vs_cpu_baseline"] = round(steps_per_s / out["cpu_baseline"]["value"], 1)
         out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
     print(json.dumps(out), flush=True)

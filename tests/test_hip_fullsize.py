@@ -1,0 +1,114 @@
+"""GPU tests at BASELINE.json's configuration sizes, through size-independent properties
+(the oracle's LU cannot be afforded at these sizes inside a test, except where noted)."""
+
+import numpy as np
+import pytest
+
+from helpers import GAMMA_DEFAULT, U_DEFAULT, edge_terminal, max_abs, remove_mean, synthetic_mesh, uniform_field_A
+
+pytestmark = pytest.mark.gpu
+
+
+def _cut_current(mesh, js, jn, x0):
+    em = mesh.edge_mesh
+    xa, xb = mesh.sites[em.edges[:, 0], 0], mesh.sites[em.edges[:, 1], 0]
+    cross = (xa < x0) != (xb < x0)
+    sign = np.where(xa < x0, 1.0, -1.0)
+    return float(((js + jn) * em.dual_edge_lengths * sign)[cross].sum())
+
+
+def test_config4_strip_500k_current_conservation_and_poisson_residual():
+    """BASELINE config 4: strip with two current terminals, ~500k sites, mu Poisson every step."""
+    from tdgl_amd import SolverOptions, TDGLSolver
+    from tdgl_amd.hipcore import poisson_matrix
+
+    mesh = synthetic_mesh(1300, 333)  # 500,955 sites
+    n = len(mesh.sites)
+    assert 4.9e5 < n < 5.1e5
+    terms = [edge_terminal(mesh, "source", -650.0), edge_terminal(mesh, "drain", 650.0)]
+    current = 0.2 * 333  # I = 0.2 * Ly
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=10**6)
+    probes = [mesh.closest_site((-325, 0)), mesh.closest_site((325, 0))]
+    solver = TDGLSolver.from_dimensionless(
+        mesh, opts, uniform_field_A(mesh, 0.0), 1.0, U_DEFAULT, GAMMA_DEFAULT, terminal_info=terms,
+        current_func={"source": current, "drain": -current}, probe_points=probes,
+    )
+    ctx = solver.ctx
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    solver.update_mu_boundary(0.0)
+    res = ctx.run(60)
+    st = ctx.get_state()
+    assert len(res["dt"]) == 60 and res["dt"][-1] > 1e-3  # the controller opened the step up
+    assert res["pcg_iters"].max() < 60
+    # (1) discrete current conservation: the injected current crosses every vertical cut
+    for x0 in (-600.3, -211.7, 0.4, 333.1, 640.2):
+        assert abs(_cut_current(mesh, st["supercurrent"], st["normal_current"], x0) - current) < 1e-7 * current
+    # (2) the returned mu solves the reference's Poisson equation for the returned psi
+    rhs = ctx.poisson_rhs(st["psi"])
+    em = mesh.edge_mesh
+    A = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
+    b = -mesh.areas * rhs
+    b -= b.mean()
+    assert np.linalg.norm(b - A @ st["mu"]) <= 2e-10 * np.linalg.norm(b)
+    assert abs(st["mu"].mean()) < 1e-12 * max(1.0, np.abs(st["mu"]).max())
+    # (3) J_n is minus the discrete gradient of mu; terminal sites stay normal
+    grad = (st["mu"][em.edges[:, 1]] - st["mu"][em.edges[:, 0]]) / em.edge_lengths
+    assert max_abs(st["normal_current"], -grad) < 1e-12 * max(1.0, np.abs(grad).max())
+    fixed = np.concatenate([t["site_indices"] for t in terms])
+    assert np.all(st["psi"][fixed] == 0)
+    assert np.abs(st["psi"]).max() < 1.0 + 1e-9
+    # (4) voltage has the sign of the current
+    assert res["mu"][-1, 0] - res["mu"][-1, 1] > 0
+
+
+def test_config2_250k_uniform_field_first_steps_match_oracle():
+    """BASELINE config 2 (250,510 sites, b = 0.1): 12 steps against the oracle (SuperLU)."""
+    from types import SimpleNamespace
+
+    from oracle import OracleSolver, run_time_loop
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    mesh = synthetic_mesh(465)
+    assert len(mesh.sites) == 250510
+    A = uniform_field_A(mesh, 0.1)
+    kw = dict(solve_time=1e9, dt_init=1e-3, save_every=10**6)
+    solver = TDGLSolver.from_dimensionless(mesh, SolverOptions(**kw, pcg_rtol=1e-11), A, 1.0, U_DEFAULT, GAMMA_DEFAULT)
+    ctx = solver.ctx
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    res = ctx.run(12)
+    got = ctx.get_state()
+    o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
+                        adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)
+    want = run_time_loop(OracleSolver(mesh, A, 1.0, U_DEFAULT, GAMMA_DEFAULT, o), o, max_steps=12)
+    assert max_abs(res["dt"], want["log"].array("dt")) < 1e-9 * res["dt"].max()
+    assert max_abs(np.abs(got["psi"]) ** 2, np.abs(want["psi"]) ** 2) < 1e-9
+    assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-9
+    assert max_abs(got["normal_current"], want["normal_current"]) < 1e-9
+    assert max_abs(got["mu"], remove_mean(want["mu"])) < 1e-9 * max(1.0, np.abs(remove_mean(want["mu"])).max())
+
+
+def test_config3_1m_sites_linearity_and_idempotence_of_operators():
+    """BASELINE config 3 mesh (1,000,431 sites): operator identities that hold at any size."""
+    from tdgl_amd.hipcore import TDGLContext
+
+    mesh = synthetic_mesh(930)
+    n = len(mesh.sites)
+    assert n == 1000431 and len(mesh.edge_mesh.edges) == 2997283
+    ctx = TDGLContext(mesh)
+    ctx.set_link_exponents(uniform_field_A(mesh, 0.1))
+    rng = np.random.default_rng(0)
+    f = rng.normal(size=n) + 1j * rng.normal(size=n)
+    g = rng.normal(size=n) + 1j * rng.normal(size=n)
+    Lf, Lg = ctx.apply_psi_laplacian(f), ctx.apply_psi_laplacian(g)
+    # linearity
+    assert max_abs(ctx.apply_psi_laplacian(2.5 * f - 1j * g), 2.5 * Lf - 1j * Lg) < 1e-11 * np.abs(Lf).max()
+    # L is Hermitian in the area-weighted inner product (covariant Laplacian, no fixed rows)
+    a = mesh.areas
+    assert abs(np.vdot(g * a, Lf) - np.conj(np.vdot(f * a, Lg))) < 1e-9 * abs(np.vdot(g * a, Lf))
+    # a constant-modulus pure-gauge state carries no supercurrent divergence in zero field
+    ctx.set_link_exponents(np.zeros((len(mesh.edge_mesh.edges), 2)))
+    assert max_abs(ctx.supercurrent(np.ones(n) * np.exp(0.3j)), 0 * mesh.edge_mesh.edge_lengths) < 1e-14
+    assert max_abs(ctx.apply_psi_laplacian(np.ones(n) * np.exp(0.3j)), np.zeros(n)) < 1e-12
+    ctx.close()
