@@ -160,6 +160,12 @@ int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn
 /* MeshOperators.set_link_exponents (operators.py:310-383): A[n_edges, 2], dimensionless.
  * Recomputes U_e = exp(-i A_e . d_e) and the covariant Laplacian / gradient values. */
 int tdgl_set_link_exponents(tdgl_ctx *ctx, const double *A);
+/* Time-dependent applied vector potential (solver.py:626-642): A_new[n_edges, 2] evaluated at
+ * this step's time, dt_prev = the previous step's dt (state["dt"]).  Stores
+ * dA/dt|_e = ((A_new - A_prev) / dt_prev) . e_hat, which enters the Poisson right-hand side and
+ * J_n of the following tdgl_run step (solver.py:508-510, 519), recomputes the link variables
+ * (operators.py:346-383) and makes A_new the new A_prev. */
+int tdgl_update_link_exponents(tdgl_ctx *ctx, const double *A_new, double dt_prev);
 /* self.epsilon (solver.py:191-216, 645-648). */
 int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon);
 /* self.mu_boundary (solver.py:289, 325-345): indexed by position in boundary_edge_indices. */

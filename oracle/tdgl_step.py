@@ -78,8 +78,17 @@ class OracleSolver:
         terminals=(),
         current_func=None,
         probe_points=None,
+        vector_potential_func=None,
+        epsilon_func=None,
     ):
+        """``vector_potential_func(t) -> A[m, 2]`` / ``epsilon_func(t) -> eps[n]`` (both already
+        dimensionless) switch on the reference's time-dependent branches (solver.py:626-648)."""
         self.mesh = mesh
+        self.vector_potential_func = vector_potential_func
+        self.epsilon_func = epsilon_func
+        self.current_A = np.asarray(link_exponents, dtype=float)
+        self.edge_unit = mesh.edge_mesh.directions / np.linalg.norm(
+            mesh.edge_mesh.directions, axis=1)[:, None]
         self.u, self.gamma = u, gamma
         self.options = options
         self.terminals = [
@@ -161,20 +170,35 @@ class OracleSolver:
         jn = -(ops.mu_gradient @ mu) - dA_dt
         return mu, js, jn
 
+    def _update_dynamic_inputs(self, time, dt):
+        """solver.py:626-648: new A(t) -> dA/dt along the edges (with the PREVIOUS step's dt)
+        and new link variables; new epsilon(t)."""
+        dA_dt = 0.0
+        if self.vector_potential_func is not None:
+            new_A = np.asarray(self.vector_potential_func(time), dtype=float)
+            dA_dt = np.einsum("ij, ij -> i", (new_A - self.current_A) / dt, self.edge_unit)
+            if not np.allclose(new_A, self.current_A):
+                self.operators.set_link_exponents(new_A)
+            self.current_A = new_A
+        if self.epsilon_func is not None:
+            self.epsilon = np.asarray(self.epsilon_func(time), dtype=float)
+        return dA_dt
+
     # -- one step ---------------------------------------------------------------------
     def update(self, state, running_state, dt, *, psi, mu, **_unused):
-        """solver.py:580-714 for static A / static epsilon / no screening.
+        """solver.py:580-714 without screening.
 
-        ``dt`` (the previous step's dt) is unused in that case: the step always runs with
+        ``dt`` (the previous step's dt) only enters dA/dt; the step itself always runs with
         ``self.tentative_dt`` (solver.py:666-668).  Returns ``(dt, psi, mu, J_s, J_n)``.
         """
         opts = self.options
         step, time = state["step"], state["time"]
         self._set_terminal_bc(time)
+        dA_dt = self._update_dynamic_inputs(time, dt)
         old_sq = np.absolute(psi) ** 2
         dt = self.tentative_dt
         psi, new_sq, dt = self._euler_step(step, psi, old_sq, mu, dt)
-        mu, js, jn = self._observables(psi)
+        mu, js, jn = self._observables(psi, dA_dt)
         if running_state is not None:
             running_state.append("dt", dt)
             if self.probe_points is not None:

@@ -262,6 +262,8 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, ctx->e_diry.upload(dy));
     HIP_TRY(ctx, ctx->e_U.alloc(ctx->m_pad));
     HIP_TRY(ctx, ctx->e_A.alloc(2 * ctx->m_pad));
+    HIP_TRY(ctx, ctx->e_Aprev.alloc(2 * ctx->m_pad));
+    HIP_TRY(ctx, ctx->e_dAdt.alloc(ctx->m_pad));
 
     // ---- Neumann boundary term (operators.py:188-230) -------------------------------
     std::vector<int32_t> s0(std::max<int64_t>(nb, 1), 0), s1(std::max<int64_t>(nb, 1), 0);
@@ -281,6 +283,7 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, ctx->b_c1.upload(c1));
     HIP_TRY(ctx, ctx->b_mu.alloc(std::max<int64_t>(nb, 1)));
     HIP_TRY(ctx, ctx->cvec.alloc(ctx->n_pad));
+    HIP_TRY(ctx, ctx->ceff.alloc(ctx->n_pad));
 
     // ---- state ------------------------------------------------------------------------
     HIP_TRY(ctx, ctx->psi[0].alloc(ctx->n_pad));
@@ -378,7 +381,7 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
         hipLaunchKernelGGL(k_psi_laplacian<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
                            ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
                            ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
-                           ctx->cvec.p, ctx->bvec.p);
+                           ctx->ceff.p, ctx->bvec.p);
     else
         hipLaunchKernelGGL(k_psi_laplacian<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
                            ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
@@ -398,13 +401,23 @@ static void launch_edge_currents(tdgl_ctx *ctx, const double2 *psi, const double
     const int grid = grid_for(ctx->m);
     if (js && jn)
         hipLaunchKernelGGL((k_edge_currents<true, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn,
+                           ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr);
     else if (js)
         hipLaunchKernelGGL((k_edge_currents<true, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn,
+                           ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr);
     else if (jn)
         hipLaunchKernelGGL((k_edge_currents<false, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn);
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn,
+                           ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr);
+}
+
+static void refresh_ceff(tdgl_ctx *ctx) {
+    hipLaunchKernelGGL(k_ceff, dim3(grid_for((int64_t)ctx->lap_pat.n_slices * WAVE)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->lap_pat.n_slices, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_slot_edge.p,
+                       ctx->lap_slot_w.p, ctx->e_inv_len.p, ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr,
+                       ctx->cvec.p, ctx->ceff.p);
 }
 
 #include "comm.inc"
@@ -412,7 +425,19 @@ static void launch_edge_currents(tdgl_ctx *ctx, const double2 *psi, const double
 #include "run.inc"
 
 // ---------------------------------------------------------------------------------------
+static int set_links_impl(tdgl_ctx *ctx, const double *A, bool dynamic, double dt_prev);
+
 extern "C" int tdgl_set_link_exponents(tdgl_ctx *ctx, const double *A) {
+    return set_links_impl(ctx, A, false, 0.0);
+}
+
+extern "C" int tdgl_update_link_exponents(tdgl_ctx *ctx, const double *A_new, double dt_prev) {
+    if (ctx && !(dt_prev > 0.0)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_update_link_exponents: dt_prev must be > 0");
+    if (ctx && !ctx->have_links) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "call tdgl_set_link_exponents first");
+    return set_links_impl(ctx, A_new, true, dt_prev);
+}
+
+static int set_links_impl(tdgl_ctx *ctx, const double *A, bool dynamic, double dt_prev) {
     CTX_GUARD(ctx);
     if (!A) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_link_exponents: null A");
     std::vector<double> tmp(2 * ctx->m_pad, 0.0);
@@ -422,6 +447,15 @@ extern "C" int tdgl_set_link_exponents(tdgl_ctx *ctx, const double *A) {
         tmp[2 * k + 1] = A[2 * e + 1];
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->e_A.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (dynamic) {
+        hipLaunchKernelGGL(k_dadt, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m, 1.0 / dt_prev,
+                           ctx->e_A.p, ctx->e_Aprev.p, ctx->e_dirx.p, ctx->e_diry.p, ctx->e_inv_len.p, ctx->e_dAdt.p);
+        ctx->has_dadt = true;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->e_Aprev.p, ctx->e_A.p, tmp.size() * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->has_dadt = false;
+    }
+    refresh_ceff(ctx);
     hipLaunchKernelGGL(k_link_variables, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m,
                        ctx->e_A.p, ctx->e_dirx.p, ctx->e_diry.p, ctx->e_U.p);
     hipLaunchKernelGGL(k_fill_laplacian, dim3(grid_for(ctx->lap_pat.n_slots)), dim3(BLOCK), 0, ctx->stream,
@@ -451,6 +485,7 @@ extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
         hipLaunchKernelGGL(k_boundary_term, dim3(grid_for(ctx->nb)), dim3(BLOCK), 0, ctx->stream, ctx->nb,
                            ctx->b_s0.p, ctx->b_s1.p, ctx->b_c0.p, ctx->b_c1.p, ctx->b_mu.p, ctx->cvec.p);
     }
+    refresh_ceff(ctx);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TDGL_OK;

@@ -148,11 +148,14 @@ struct tdgl_ctx {
     tdgl::DevBuf<int32_t> e0, e1;
     tdgl::DevBuf<double> e_inv_len, e_dirx, e_diry;
     tdgl::DevBuf<double2> e_U;
-    tdgl::DevBuf<double> e_A;             // staging for link exponents [2 * m_pad]
+    tdgl::DevBuf<double> e_A, e_Aprev;    // link exponents now / at the previous step [2 * m_pad]
+    tdgl::DevBuf<double> e_dAdt;          // dA/dt along the edges (time-dependent A), else unused
+    bool has_dadt = false;
     // boundary term: c = mu_boundary_laplacian @ mu_boundary
     tdgl::DevBuf<int32_t> b_s0, b_s1;
     tdgl::DevBuf<double> b_c0, b_c1, b_mu;
-    tdgl::DevBuf<double> cvec;
+    tdgl::DevBuf<double> cvec;            // boundary part
+    tdgl::DevBuf<double> ceff;            // cvec + divergence(dA/dt): what the rhs kernel reads
 
     // ---- state ---------------------------------------------------------------------
     tdgl::DevBuf<double2> psi[2];

@@ -123,6 +123,7 @@ SIGNATURES = {
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),
     "tdgl_comm_init_callbacks": (C.c_int, [_CTX, HALO_FN, ALLREDUCE_FN, C.c_void_p]),
     "tdgl_set_link_exponents": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_update_link_exponents": (C.c_int, [_CTX, c_f64p, C.c_double]),
     "tdgl_set_epsilon": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_mu_boundary": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_state": (C.c_int, [_CTX, c_f64p, c_f64p]),

@@ -234,6 +234,13 @@ class TDGLContext:
             raise ValueError(f"Unexpected shape for vector_potential: {A.shape}.")
         self._chk(self._lib.tdgl_set_link_exponents(self._ctx, p_f64(A)))
 
+    def update_link_exponents(self, A_new, dt_prev):
+        """Time-dependent A: new link exponents + dA/dt for the next step (solver.py:626-642)."""
+        A_new = f64(A_new)
+        if A_new.shape != (self.m, 2):
+            raise ValueError(f"Unexpected shape for vector_potential: {A_new.shape}.")
+        self._chk(self._lib.tdgl_update_link_exponents(self._ctx, p_f64(A_new), float(dt_prev)))
+
     def set_epsilon(self, eps):
         eps = f64(np.broadcast_to(eps, (self.n,)))
         self._chk(self._lib.tdgl_set_epsilon(self._ctx, p_f64(eps)))

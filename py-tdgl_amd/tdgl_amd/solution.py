@@ -67,6 +67,32 @@ class Solution:
     def times(self) -> np.ndarray:
         return np.array([s.time for s in self.saved_steps])
 
+    # -- sheet current densities on the sites, in current_units / length_units -------------------
+    def _k0(self) -> float:
+        """K0 in ``current_units / length_units`` (`tdgl/solution/solution.py:192`)."""
+        from .device import CURRENT_UNITS, LENGTH_UNITS
+
+        dev = self.device
+        return dev.K0 * LENGTH_UNITS[dev.length_units] / CURRENT_UNITS[self.options.current_units]
+
+    def _site_vector(self, quantity_on_edges) -> np.ndarray:
+        # magnitude * unit direction of the edge->site average (`tdgl/solution/data.py:48-65`)
+        return self.device.mesh.get_quantity_on_site(quantity_on_edges)
+
+    @property
+    def supercurrent_density(self) -> np.ndarray:
+        """K_s on the sites, shape (n, 2) (`tdgl/solution/solution.py:186-194`)."""
+        return self._k0() * self._site_vector(self.tdgl_data.supercurrent)
+
+    @property
+    def normal_current_density(self) -> np.ndarray:
+        return self._k0() * self._site_vector(self.tdgl_data.normal_current)
+
+    @property
+    def current_density(self) -> np.ndarray:
+        """Total sheet current density K = K_s + K_n (`tdgl/solution/solution.py:230-237`)."""
+        return self.supercurrent_density + self.normal_current_density
+
     def current_through_cut(self, x0: float) -> float:
         """Total dimensionless sheet current crossing the vertical line x = x0 (in units of
         xi), summed over the mesh edges that cross it: ``sum_e (J_s + J_n)_e s_e sign`` with

@@ -11,8 +11,10 @@ What runs where:
   (``tdgl_run``); Python is entered once per ``save_every`` steps (or once per step when the
   terminal currents are a function of time, because the callable lives in Python).
 
-Not supported (raise): ``include_screening``, time-dependent ``applied_vector_potential`` /
-``disorder_epsilon``, HDF5 output.
+Time-dependent ``applied_vector_potential`` (a ``Parameter`` with a keyword-only ``t``) and
+``disorder_epsilon`` are evaluated in Python once per step and uploaded; dA/dt and the link
+variables are then formed on the device (``tdgl_update_link_exponents``).
+Not supported (raise): ``include_screening``, HDF5 output.
 """
 
 import inspect
@@ -106,37 +108,47 @@ class TDGLSolver:
         self.dynamic_vector_potential = bool(
             getattr(applied_vector_potential, "time_dependent", False)
         )
-        if self.dynamic_vector_potential:
-            raise NotImplementedError(
-                "Time-dependent applied vector potentials are not supported yet."
-            )
         self.applied_vector_potential = applied_vector_potential
         self.A_scale = device.field_scale(options.field_units)
         ex, ey = self.edge_centers[:, 0], self.edge_centers[:, 1]
-        if callable(applied_vector_potential):
-            A = np.asarray(applied_vector_potential(ex, ey, self.z0))
+        self.vector_potential_func = None
+        if self.dynamic_vector_potential:
+            # solver.py:347-362: A(t) on the edge centres, scaled to dimensionless units
+            def vector_potential_func(t):
+                return self.A_scale * np.asarray(applied_vector_potential(ex, ey, self.z0, t=t))[:, :2]
+
+            self.vector_potential_func = vector_potential_func
+            A = vector_potential_func(0)
+        elif callable(applied_vector_potential):
+            A = self.A_scale * np.asarray(applied_vector_potential(ex, ey, self.z0))[:, :2]
         else:
-            A = uniform_field_vector_potential(ex, ey, float(applied_vector_potential))
-        A = self.A_scale * np.asarray(A)[:, :2]
+            A = self.A_scale * uniform_field_vector_potential(ex, ey, float(applied_vector_potential))[:, :2]
         if A.shape != self.edge_centers.shape:
             raise ValueError(f"Unexpected shape for vector_potential: {A.shape}.")
         self.current_A_applied = A
 
         # ---- disorder parameter epsilon on the sites (solver.py:191-216) ----------------
+        self.epsilon_func = None
+        self.dynamic_epsilon = False
         if callable(disorder_epsilon):
             spec = inspect.getfullargspec(disorder_epsilon)
-            if "t" in spec.kwonlyargs:
-                raise NotImplementedError("Time-dependent disorder_epsilon is not supported yet.")
+            self.dynamic_epsilon = "t" in spec.kwonlyargs
             vectorized = spec.kwonlydefaults is not None and spec.kwonlydefaults.get("vectorized", False)
-            if vectorized:
-                epsilon = np.asarray(disorder_epsilon(self.sites), dtype=float)
+
+            def evaluate(**kw):  # solver.py:211-214, 364-381
+                if vectorized:
+                    return np.asarray(disorder_epsilon(self.sites, **kw), dtype=float)
+                return np.array([float(disorder_epsilon(r, **kw)) for r in self.sites])
+
+            if self.dynamic_epsilon:
+                self.epsilon_func = lambda t: evaluate(t=t)  # noqa: E731
+                epsilon = evaluate(t=0)
             else:
-                epsilon = np.array([float(disorder_epsilon(r)) for r in self.sites])
+                epsilon = evaluate()
         else:
             epsilon = float(disorder_epsilon) * np.ones(len(self.sites))
         if np.any(epsilon > 1):
             raise ValueError("The disorder parameter epsilon must be <= 1")
-        self.dynamic_epsilon = False
         self.disorder_epsilon = disorder_epsilon
         self.epsilon = epsilon
 
@@ -173,7 +185,8 @@ class TDGLSolver:
     @classmethod
     def from_dimensionless(cls, mesh, options: SolverOptions, link_exponents, epsilon=1.0,
                            u: float = 5.79, gamma: float = 10.0, terminal_info=(),
-                           current_func=None, probe_points=None, device=None) -> "TDGLSolver":
+                           current_func=None, probe_points=None, device=None,
+                           vector_potential_func=None, epsilon_func=None) -> "TDGLSolver":
         """Build a solver directly from dimensionless inputs -- the arrays the reference's
         ``__init__`` ends up with (solver.py:185, 214, 225, 254-256): ``A[m, 2]``,
         ``epsilon[n]``, ``TerminalInfo`` records and ``t -> {name: dimensionless current}``.
@@ -191,7 +204,11 @@ class TDGLSolver:
         self.sites = mesh.sites
         self.applied_vector_potential = None
         self.disorder_epsilon = epsilon
-        self.dynamic_vector_potential = self.dynamic_epsilon = False
+        # optional time dependence: t -> A[m, 2] / t -> epsilon[n], already dimensionless
+        self.vector_potential_func = vector_potential_func
+        self.epsilon_func = epsilon_func
+        self.dynamic_vector_potential = vector_potential_func is not None
+        self.dynamic_epsilon = epsilon_func is not None
         A = np.asarray(link_exponents, dtype=float)
         if A.shape != (self.num_edges, 2):
             raise ValueError(f"Unexpected shape for vector_potential: {A.shape}.")
@@ -274,6 +291,18 @@ class TDGLSolver:
             self.ctx.set_mu_boundary(self.mu_boundary)
         return changed
 
+    def update_dynamic_inputs(self, time: float, dt_prev: float) -> None:
+        """solver.py:626-648: re-evaluate A(t) (-> link variables and dA/dt with the previous
+        step's dt) and epsilon(t) before a step."""
+        if self.dynamic_vector_potential:
+            self.current_A_applied = np.asarray(self.vector_potential_func(time), dtype=float)
+            self.ctx.update_link_exponents(self.current_A_applied, dt_prev)
+        if self.dynamic_epsilon:
+            self.epsilon = np.asarray(self.epsilon_func(time), dtype=float)
+            if np.any(self.epsilon > 1):
+                raise ValueError("The disorder parameter epsilon must be <= 1")
+            self.ctx.set_epsilon(self.epsilon)
+
     # -- one step through the reference's method seam ---------------------------------------------
     def update(self, state: Dict[str, numbers.Real], running_state, dt: float, *, psi, mu,
                supercurrent=None, normal_current=None, induced_vector_potential=None,
@@ -289,6 +318,7 @@ class TDGLSolver:
             ctx.set_state(psi, mu)
         ctx.set_loop_state(state["step"], state["time"], state.get("dt", dt))
         self.update_mu_boundary(state["time"])
+        self.update_dynamic_inputs(state["time"], dt)
         res = ctx.run(1, np.inf)
         out = ctx.get_state()
         self._device_holds = (out["psi"], out["mu"])
@@ -301,7 +331,12 @@ class TDGLSolver:
         a_ind = (
             np.zeros((self.num_edges, 2)) if induced_vector_potential is None else induced_vector_potential
         )
-        return SolverResult(step_dt, out["psi"], out["mu"], out["supercurrent"], out["normal_current"], a_ind)
+        extra = []
+        if self.dynamic_vector_potential:
+            extra.append(self.current_A_applied)
+        if self.dynamic_epsilon:
+            extra.append(self.epsilon)
+        return SolverResult(step_dt, out["psi"], out["mu"], out["supercurrent"], out["normal_current"], a_ind, *extra)
 
     # -- the whole simulation ------------------------------------------------------------------------
     def solve(self) -> Optional[Solution]:
@@ -344,9 +379,12 @@ class TDGLSolver:
             while True:
                 if save and i % opts.save_every == 0:
                     save_step()
-                chunk = 1 if self.dynamic_currents else opts.save_every - (i % opts.save_every)
-                self.update_mu_boundary(ctx.loop_state()["time"] if self.dynamic_currents else 0.0)
-                t_before = ctx.loop_state()["time"]
+                per_step = self.dynamic_currents or self.dynamic_vector_potential or self.dynamic_epsilon
+                chunk = 1 if per_step else opts.save_every - (i % opts.save_every)
+                ls = ctx.loop_state()
+                self.update_mu_boundary(ls["time"] if self.dynamic_currents else 0.0)
+                self.update_dynamic_inputs(ls["time"], ls["dt"])
+                t_before = ls["time"]
                 res = ctx.run(chunk, end_time)
                 k = len(res["dt"])
                 n_steps[name] += k

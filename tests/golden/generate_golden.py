@@ -161,6 +161,13 @@ def run_reference(solver, psi0, options, snapshot_steps=()):
     n = len(psi0)
     calls = []
     snaps = {}
+    extra_names, extra_values = [], []
+    if solver.dynamic_vector_potential:  # solver.py:756-757
+        extra_names.append("applied_vector_potential")
+        extra_values.append(solver.current_A_applied)
+    if solver.dynamic_epsilon:  # solver.py:761-762
+        extra_names.append("epsilon")
+        extra_values.append(solver.epsilon)
 
     def logged_update(state, running_state, dt, **values):
         result = solver.update(state, running_state, dt, **values)
@@ -183,8 +190,8 @@ def run_reference(solver, psi0, options, snapshot_steps=()):
         function=logged_update,
         options=options,
         data_handler=handler,
-        initial_values=[psi0, np.zeros(n), np.zeros(m), np.zeros(m), np.zeros((m, 2))],
-        names=["psi", "mu", "supercurrent", "normal_current", "induced_vector_potential"],
+        initial_values=[psi0, np.zeros(n), np.zeros(m), np.zeros(m), np.zeros((m, 2))] + extra_values,
+        names=["psi", "mu", "supercurrent", "normal_current", "induced_vector_potential"] + extra_names,
         fixed_values=(),
         fixed_names=(),
         running_names_and_sizes=sizes,
@@ -389,6 +396,39 @@ def main():
     out = run_reference(s, psi0, o)
     print("retry calls:", len(out["call_dt"]), "dt min/max", out["call_dt"].min(), out["call_dt"].max())
     save("traj_retry_small", b=0.8, **options_arrays(o), **out)
+
+    # (4g) time-dependent applied field (ramp) AND time-dependent epsilon (moving hot spot):
+    # exercises dA/dt in the Poisson right-hand side and J_n, and the per-step link update
+    # (solver.py:626-648, operators.py:346-383)
+    o = SolverOptions(solve_time=8.0, dt_init=1e-4, save_every=100)
+    probes = [small.closest_site((-5, 0)), small.closest_site((5, 0))]
+    s, psi0, _ = make_ref_solver(small, uniform_field_A(small, 0.0), o, probe_points=probes)
+    A_full = uniform_field_A(small, 0.6)
+
+    def ramp_A(x, y, z, *, t=0):
+        a2 = min(t / 5.0, 1.0) * A_full
+        return np.column_stack([a2, np.zeros(len(a2))])
+
+    def hot_spot(r, *, t=0, vectorized=True):
+        c = np.array([-6.0 + 1.5 * t, 1.0])
+        return 1.0 - 0.6 * np.exp(-((r - c) ** 2).sum(axis=1) / 4.0)
+
+    s.dynamic_vector_potential = True
+    s.applied_vector_potential = ramp_A
+    s.A_scale = 1.0
+    s.edge_centers = small.edge_mesh.centers
+    s.z0 = np.zeros(len(s.edge_centers))
+    s.current_A_applied = ramp_A(None, None, None, t=0)[:, :2]
+    s.operators.set_link_exponents(s.current_A_applied)
+    s.dynamic_epsilon = True
+    s.disorder_epsilon = hot_spot
+    s.vectorized_epsilon = True
+    s.sites = small.sites
+    s.epsilon = hot_spot(small.sites, t=0)
+    out = run_reference(s, psi0, o, snapshot_steps=(0, 20, 60))
+    print("dynamic calls:", len(out["call_dt"]), "min|psi|^2", (np.abs(out["final_psi"]) ** 2).min())
+    save("traj_dynamic_small", b_final=0.6, probe_points=np.array(probes), A_full=A_full,
+         **options_arrays(o), **out)
 
     # ---- (5) runner bookkeeping: thermalise + save_every not dividing the step count ----
     o = SolverOptions(solve_time=1.0, skip_time=0.5, dt_init=1e-3, save_every=7)

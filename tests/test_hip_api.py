@@ -1,0 +1,119 @@
+"""GPU tests written against the public API the way the reference's own tests are
+(`tdgl/test/test_solve.py`): Device / Layer / Polygon in physical units, `tdgl.solve`,
+`SolverOptions`, terminal currents, physical assertions."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _transport_device():
+    import tdgl_amd as tdgl
+    from tdgl_amd.geometry import box
+
+    layer = tdgl.Layer(coherence_length=0.5, london_lambda=2.0, thickness=0.1)
+    film = tdgl.Polygon("film", points=box(30.0, 4.0))
+    source = tdgl.Polygon("source", points=box(0.2, 4.0, center=(-15.0, 0)))
+    drain = tdgl.Polygon("drain", points=box(0.2, 4.0, center=(15.0, 0)))
+    device = tdgl.Device("strip", layer=layer, film=film, terminals=[source, drain],
+                         probe_points=[(-10.0, 0.0), (10.0, 0.0)], length_units="um")
+    device.make_mesh(max_edge_length=0.25)
+    return device
+
+
+@pytest.mark.parametrize("current", [5.0, lambda t: 10.0])
+@pytest.mark.parametrize("field", [0.0, 1.0])
+@pytest.mark.parametrize("terminal_psi", [0.0, None])
+def test_source_drain_current(current, field, terminal_psi):
+    """cf. test_source_drain_current, tdgl/test/test_solve.py:15-125."""
+    import tdgl_amd as tdgl
+
+    device = _transport_device()
+    if callable(current):
+        def terminal_currents(t):
+            return dict(source=current(t), drain=-current(t))
+        total = current(0)
+    else:
+        terminal_currents = dict(source=current, drain=-current)
+        total = current
+    with pytest.raises(tdgl.SolverOptionsError):
+        tdgl.solve(device, tdgl.SolverOptions(solve_time=1, sparse_solver="bogus"), terminal_currents=terminal_currents)
+    with pytest.raises(ValueError, match="epsilon must be <= 1"):
+        tdgl.solve(device, tdgl.SolverOptions(solve_time=1), disorder_epsilon=2.0)
+    with pytest.raises(ValueError, match="sum of all terminal currents must be 0"):
+        tdgl.solve(device, tdgl.SolverOptions(solve_time=1), terminal_currents=dict(source=1.0, drain=0.0))
+    options = tdgl.SolverOptions(solve_time=20, dt_init=1e-3, field_units="uT", current_units="uA",
+                                 save_every=100, terminal_psi=terminal_psi)
+    solution = tdgl.solve(device, options, applied_vector_potential=field, terminal_currents=terminal_currents)
+    assert isinstance(solution, tdgl.Solution) and len(solution.saved_steps) >= 2
+    # current through five cross-sections = the applied current (the reference asserts rtol=0.1
+    # on an interpolated path; the finite-volume sum is conserved to round-off)
+    j_scale = device.current_scale("uA")
+    for x in np.linspace(-12, 12, 5) + 0.013:
+        measured = solution.current_through_cut(x / device.coherence_length) / j_scale * device.coherence_length
+        assert np.isclose(measured, total, rtol=1e-6), (x, measured, total)
+    v = solution.dynamics.voltage()
+    assert v.shape == solution.dynamics.dt.shape
+    dtw = solution.dynamics.dt[len(v) // 2:]
+    assert (v[len(v) // 2:] * dtw).sum() / dtw.sum() > 0  # time-averaged voltage follows the current
+
+
+def test_reference_physical_pin_kmax():
+    """The only place the reference pins its unit conversion numerically
+    (tdgl/test/test_solve.py:128-176): a 2 x 1 um bar, xi = 0.1, lambda = 0.075, d = 0.05 um in
+    0.1 mT carries K_max ~ 450 uA/um (rtol 5e-2 ON THE REFERENCE'S Triangle MESH) after 2 tau_0.
+    K_max sits on boundary sites, where the reference's edge->site average (mean of F_e e_hat over
+    the incident edges, halved) depends on how the mesh edges meet the boundary: on the jittered
+    triangular lattice used here it converges to 411 uA/um (408 / 412 / 411 at pitch 0.045 / 0.03 /
+    0.02 um, same number from the oracle).  So: within 12 % of the reference's figure -- a wrong
+    Phi_0, mu_0, factor 2 pi or factor 4 in Bc2 / K0 / A_scale would be off by >= 2x -- and equal
+    to the oracle run through the same unit conversion."""
+    import tdgl_amd as tdgl
+    from tdgl_amd.geometry import box
+
+    layer = tdgl.Layer(coherence_length=0.1, london_lambda=0.075, thickness=0.05)
+    film = tdgl.Polygon("film", points=box(2, 1, points=301))
+    device = tdgl.Device("bar", layer=layer, film=film, length_units="um")
+    device.make_mesh(max_edge_length=0.05)
+    options = tdgl.SolverOptions(solve_time=2, field_units="mT", current_units="uA")
+    solution = tdgl.solve(device, options, applied_vector_potential=0.1)
+    K = solution.current_density
+    k_max = np.sqrt(K[:, 0] ** 2 + K[:, 1] ** 2).max()
+    assert np.isclose(k_max, 450, rtol=0.12), k_max
+    from types import SimpleNamespace
+
+    from helpers import uniform_field_A
+    from oracle import OracleSolver, run_time_loop
+
+    mesh = device.mesh
+    o = SimpleNamespace(solve_time=2.0, skip_time=0.0, dt_init=1e-6, dt_max=0.1, adaptive=True, adaptive_window=10,
+                        max_solve_retries=10, adaptive_time_step_multiplier=0.25, terminal_psi=0.0, save_every=100)
+    b = 0.1e-3 / device.Bc2
+    want = run_time_loop(OracleSolver(mesh, uniform_field_A(mesh, b), 1.0, 5.79, 10.0, o), o)
+    k_ref = device.K0 * np.linalg.norm(
+        mesh.get_quantity_on_site(want["supercurrent"] + want["normal_current"]), axis=1).max()
+    assert np.isclose(k_max, k_ref, rtol=1e-6), (k_max, k_ref)
+
+
+def test_time_dependent_field_through_the_public_api():
+    """Field ramp written like the reference's docs: LinearRamp(...) * ConstantField(...)."""
+    import tdgl_amd as tdgl
+    from tdgl_amd.geometry import box
+
+    layer = tdgl.Layer(coherence_length=0.5, london_lambda=2.0, thickness=0.1)
+    device = tdgl.Device("sq", layer=layer, film=tdgl.Polygon("film", points=box(8.0)), length_units="um")
+    device.make_mesh(max_edge_length=0.25)
+    ramp = tdgl.LinearRamp(tmin=0, tmax=4) * tdgl.ConstantField(1.2, field_units="mT", length_units="um")
+    assert ramp.time_dependent
+    options = tdgl.SolverOptions(solve_time=6, dt_init=1e-3, field_units="mT", save_every=50)
+    solution = tdgl.solve(device, options, applied_vector_potential=ramp)
+    static = tdgl.solve(device, tdgl.SolverOptions(solve_time=6, dt_init=1e-3, field_units="mT", save_every=50),
+                        applied_vector_potential=1.2)
+    # after the ramp has ended both runs sit in the same field: screening currents agree in scale
+    k_dyn = np.linalg.norm(solution.current_density, axis=1).max()
+    k_sta = np.linalg.norm(static.current_density, axis=1).max()
+    assert 0.5 < k_dyn / k_sta < 2.0
+    # while the field changes, dA/dt drives a normal current: J_n != 0 early in the ramp
+    early = solution.saved_steps[1]
+    assert np.abs(early.normal_current).max() > 1e-6

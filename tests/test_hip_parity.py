@@ -273,6 +273,30 @@ def test_trajectory_time_dependent_current_free_terminal_psi():
     assert [s.step for s in sol.saved_steps] == list(g["save_step"])
 
 
+def test_trajectory_time_dependent_field_and_epsilon():
+    """dA/dt in the Poisson right-hand side and J_n, per-step link update, per-step epsilon."""
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    g = load_golden("traj_dynamic_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    o = options_from_golden(g)
+    opts = SolverOptions(solve_time=o.solve_time, dt_init=o.dt_init, dt_max=o.dt_max, save_every=o.save_every,
+                         pcg_rtol=1e-11)
+    A_full = g["A_full"]
+
+    def hot_spot(t):
+        c = np.array([-6.0 + 1.5 * t, 1.0])
+        return 1.0 - 0.6 * np.exp(-((mesh.sites - c) ** 2).sum(axis=1) / 4.0)
+
+    solver = TDGLSolver.from_dimensionless(
+        mesh, opts, 0.0 * A_full, hot_spot(0.0), U_DEFAULT, GAMMA_DEFAULT,
+        probe_points=[int(p) for p in g["probe_points"]],
+        vector_potential_func=lambda t: min(t / 5.0, 1.0) * A_full, epsilon_func=hot_spot,
+    )
+    sol = solver.solve()
+    _assert_hip_trajectory(g, sol, 1e-8)  # 265 steps, no instability in this run
+
+
 def test_trajectory_with_dt_retries():
     g = load_golden("traj_retry_small")
     mesh = reference_mesh(load_golden("mesh_small"))

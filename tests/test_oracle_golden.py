@@ -198,6 +198,26 @@ def test_trajectory_time_dependent_current_free_terminal_psi():
     _assert_trajectory(g, mesh, out, 1e-12)
 
 
+def test_trajectory_time_dependent_field_and_epsilon():
+    g = load_golden("traj_dynamic_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    opts = options_from_golden(g)
+    A_full = g["A_full"]
+    solver = OracleSolver(
+        mesh, 0.0 * A_full, _hot_spot(mesh.sites, 0.0), U_DEFAULT, GAMMA_DEFAULT, opts,
+        probe_points=[int(p) for p in g["probe_points"]],
+        vector_potential_func=lambda t: min(t / 5.0, 1.0) * A_full,
+        epsilon_func=lambda t: _hot_spot(mesh.sites, t),
+    )
+    out = run_time_loop(solver, opts)
+    _assert_trajectory(g, mesh, out, 1e-12)
+
+
+def _hot_spot(r, t):
+    c = np.array([-6.0 + 1.5 * t, 1.0])
+    return 1.0 - 0.6 * np.exp(-((r - c) ** 2).sum(axis=1) / 4.0)
+
+
 def test_trajectory_with_dt_retries():
     g = load_golden("traj_retry_small")
     mesh = reference_mesh(load_golden("mesh_small"))
