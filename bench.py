@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--smoother", default="chebyshev", choices=["chebyshev", "jacobi"])
     ap.add_argument("--nu", type=int, default=2, help="smoother degree on the coarse levels")
     ap.add_argument("--nu-fine", type=int, default=1, help="smoother degree on level 0")
-    ap.add_argument("--no-extrapolate", action="store_true")
+    ap.add_argument("--extrapolate", type=int, default=2, help="initial-guess extrapolation order (0, 1, 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
@@ -202,7 +202,7 @@ def main():
         log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
     ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                             edge_currents_every_step=True, smoother=args.smoother,
-                            extrapolate=not args.no_extrapolate, nu_fine=args.nu_fine)
+                            extrapolate=args.extrapolate, nu_fine=args.nu_fine)
     h = ctx.hierarchy
     log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")
     ctx.begin_stage()

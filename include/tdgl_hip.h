@@ -101,7 +101,8 @@ typedef struct {
                                          reference's update(); 0: only on tdgl_get_state */
     int32_t smoother;     /* 0 = damped Jacobi, 1 = Chebyshev in D^-1 A                */
     double cheb_lo;       /* Chebyshev interval [cheb_lo * rho, rho]                   */
-    int32_t extrapolate;  /* 1: initial guess mu^n + (dt'/dt)(mu^n - mu^{n-1})          */
+    int32_t extrapolate;  /* initial guess: 0 = mu^n, 1 = linear, 2 = quadratic extrapolation
+                             in time through the last two / three solutions              */
     int32_t nu_fine;      /* smoother degree on level 0 (0 = nu).  Default 1 with nu = 2:
                              halves the level-0 passes per cycle for ~5 % more iterations  */
 } tdgl_poisson_options;

@@ -499,7 +499,7 @@ extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu
     ctx->have_state = true;
     ctx->lap_valid = false;
     ctx->currents_valid = false;
-    ctx->prev_dt = 0.0;  // no mu history: the next solve starts from mu itself
+    ctx->prev_dt = ctx->prev_dt2 = 0.0;  // no mu history: the next solve starts from mu itself
     return TDGL_OK;
 }
 

@@ -97,7 +97,7 @@ struct AmgLevel {
 };
 
 // scalars of the PCG recurrence, resident on the device
-enum Scal { S_RR = 0, S_BB, S_COUNT = 4 };
+enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_COUNT = 4 };
 
 // what a step reports back to the host at its synchronisation point
 struct StepStatus {
@@ -172,11 +172,11 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
-    tdgl::DevBuf<double> part_rz[2], part_pq, part_rr, part_tmp;  // NB per-workgroup partials each
+    tdgl::DevBuf<double> part_rz[2], part_pq, part_rr[2], part_tmp;  // NB per-workgroup partials each
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
-    tdgl::DevBuf<double> mu_prev;         // mu^{n-1} for the extrapolated initial guess
-    double prev_dt = 0.0;                 // dt of the step that produced mu (0: no history)
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 1, 1};
+    tdgl::DevBuf<double> mu_prev, mu_prev2;  // mu^{n-1}, mu^{n-2} for the extrapolated initial guess
+    double prev_dt = 0.0, prev_dt2 = 0.0;    // dt of the steps that produced mu / mu_prev (0: no history)
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 2, 1};
     int32_t last_pcg_iters = 0;
     double last_relres = 0.0;
 

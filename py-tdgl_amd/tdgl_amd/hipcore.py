@@ -107,7 +107,7 @@ class TDGLContext:
     # -- Poisson set-up -------------------------------------------------------------------
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
-                      cheb_lo=0.1, extrapolate=True, nu_fine=1) -> Hierarchy:
+                      cheb_lo=0.1, extrapolate=2, nu_fine=1) -> Hierarchy:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
         operators.py:305-308) + upload."""
         k = self._keep
@@ -218,13 +218,13 @@ class TDGLContext:
 
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
-                            extrapolate=True, nu_fine=1):
+                            extrapolate=2, nu_fine=1):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
-                                int(bool(extrapolate)), int(nu_fine))
+                                int(extrapolate), int(nu_fine))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
-                                    smoother=kind, cheb_lo=cheb_lo, extrapolate=bool(extrapolate))
+                                    smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
 
     # -- inputs ---------------------------------------------------------------------------
