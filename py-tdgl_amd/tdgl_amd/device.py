@@ -26,7 +26,7 @@ import numpy as np
 
 from .finite_volume import Mesh
 from .geometry import close_curve
-from .meshgen import rectangle_mesh_points
+from .meshgen import polygon_mesh, rectangle_mesh_points
 
 PHI_0 = 2.067833848e-15  # Wb, magnetic flux quantum h / 2e
 MU_0 = 1.25663706212e-6  # N / A^2
@@ -364,19 +364,24 @@ class Device:
     ) -> None:
         """Mesh the film (`Device.make_mesh`, device.py:520-566).
 
-        The built-in generator covers rectangular, hole-free films with a jittered
-        triangular lattice whose edges do not exceed ``max_edge_length`` (default: one
+        Rectangular, hole-free films get a jittered triangular lattice; any other polygon
+        (holes included) a boundary-conforming Delaunay mesh of such a lattice
+        (`meshgen.polygon_mesh`).  Edges do not exceed ``max_edge_length`` (default: one
         coherence length, as in the reference).  ``smooth`` is accepted and ignored (the
-        lattice is already near-equilateral).  For anything else, mesh externally and call
+        lattice is already near-equilateral).  A mesh made elsewhere can be installed with
         :meth:`mesh_from_triangulation`.
         """
-        if self.holes or not self.film.is_rectangle():
-            raise NotImplementedError(
-                "The built-in mesher handles rectangular films without holes; use"
-                " Device.mesh_from_triangulation(points, triangles) for other geometries."
-            )
         if max_edge_length is None or max_edge_length <= 0:
             max_edge_length = 1.0 * self.layer.coherence_length
+        if self.holes or not self.film.is_rectangle():
+            # general polygon (with holes): boundary-conforming Delaunay mesh
+            while True:
+                pts, tri = polygon_mesh(self.film.points, [h.points for h in self.holes], max_edge_length, seed=seed)
+                if min_points is None or len(pts) >= min_points:
+                    break
+                max_edge_length *= 0.9
+            self.mesh_from_triangulation(pts, tri)
+            return
         (x0, y0), (x1, y1) = self.film.bbox
         width, height = x1 - x0, y1 - y0
         while True:

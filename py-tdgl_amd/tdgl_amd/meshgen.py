@@ -64,3 +64,122 @@ def rectangle_mesh_points(
     pitch = 0.9 * max_edge_length
     pts = hex_jitter_points(width, height, pitch=pitch, seed=seed)
     return pts, triangulate(pts)
+
+
+# ---------------------------------------------------------------------------------------
+# General polygons (with holes).  The reference calls meshpy/Triangle
+# (`tdgl/device/meshing.py:15-123`); here: boundary points at spacing <= h on every polygon
+# edge, a jittered triangular lattice in the interior kept >= 0.6 h away from the boundary, a
+# Delaunay triangulation, triangles outside the domain removed, and boundary segments split
+# until (i) every segment is a triangle edge and (ii) no point lies inside a segment's diametral
+# circle (Gabriel condition).  (ii) puts the circumcentre of every boundary triangle on the
+# domain side of its boundary edge, so all Voronoi dual lengths / cell areas are the plain
+# finite-volume ones (positive), exactly what `Mesh.from_triangulation` computes.
+def _points_in_poly(poly, pts):
+    from matplotlib import path as mpath
+
+    poly = np.asarray(poly, dtype=float)
+    if not np.allclose(poly[0], poly[-1]):  # Path(closed=True) ignores the last vertex
+        poly = np.concatenate([poly, poly[:1]])
+    return mpath.Path(poly, closed=True).contains_points(pts)
+
+
+def _segment_distance(pts, a, b):
+    """Distance of every point to the segments a[k] -> b[k]; returns the minimum over segments."""
+    out = np.full(len(pts), np.inf)
+    for p0, p1 in zip(a, b):
+        d = p1 - p0
+        t = np.clip(((pts - p0) @ d) / (d @ d), 0.0, 1.0)
+        out = np.minimum(out, np.linalg.norm(pts - (p0 + t[:, None] * d), axis=1))
+    return out
+
+
+def polygon_mesh(film, holes=(), max_edge_length=1.0, seed=0, max_rounds=12):
+    """Boundary-conforming Delaunay mesh of ``film`` minus ``holes`` (closed or open ``(k, 2)``
+    vertex arrays) with no edge longer than ``max_edge_length``.  Returns ``(points, triangles)``."""
+    pitch = 0.65 * float(max_edge_length)
+    for _ in range(6):
+        pts, tri = _polygon_mesh_at_pitch(film, holes, pitch, seed, max_rounds)
+        e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
+        longest = np.linalg.norm(pts[e[:, 0]] - pts[e[:, 1]], axis=1).max()
+        if longest <= max_edge_length:
+            return pts, tri
+        pitch *= 0.97 * max_edge_length / longest
+    raise RuntimeError("polygon_mesh: could not satisfy max_edge_length")  # pragma: no cover
+
+
+def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
+    h = float(h)
+    loops = []
+    for poly in [film] + list(holes):
+        poly = np.asarray(poly, dtype=float)
+        if np.allclose(poly[0], poly[-1]):
+            poly = poly[:-1]
+        loops.append(poly)
+
+    def resample(loop):
+        pts = []
+        for p0, p1 in zip(loop, np.roll(loop, -1, axis=0)):
+            k = max(1, int(np.ceil(np.linalg.norm(p1 - p0) / h)))
+            pts.append(p0 + (p1 - p0) * (np.arange(k) / k)[:, None])
+        return np.concatenate(pts)
+
+    bloops = [resample(lp) for lp in loops]
+    (x0, y0), (x1, y1) = loops[0].min(axis=0), loops[0].max(axis=0)
+    lattice = hex_jitter_points(x1 - x0 + 2 * h, y1 - y0 + 2 * h, pitch=h, seed=seed,
+                                center=(0.5 * (x0 + x1), 0.5 * (y0 + y1)))
+    keep = _points_in_poly(loops[0], lattice)
+    for hole in loops[1:]:
+        keep &= ~_points_in_poly(hole, lattice)
+    lattice = lattice[keep]
+    seg_a = np.concatenate(loops)
+    seg_b = np.concatenate([np.roll(lp, -1, axis=0) for lp in loops])
+    lattice = lattice[_segment_distance(lattice, seg_a, seg_b) >= 0.6 * h]
+
+    for _ in range(max_rounds):
+        nb = [len(b) for b in bloops]
+        pts = np.concatenate(bloops + [lattice])
+        tri = Delaunay(pts).simplices
+        cent = pts[tri].mean(axis=1)
+        inside = _points_in_poly(loops[0], cent)
+        for hole in loops[1:]:
+            inside &= ~_points_in_poly(hole, cent)
+        tri = tri[inside]
+        edges = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
+        edge_set = set(map(tuple, edges))
+        split = False
+        off = 0
+        new_loops = []
+        for b, n_b in zip(bloops, nb):
+            idx = off + np.arange(n_b)
+            nxt = off + (np.arange(n_b) + 1) % n_b
+            mids = 0.5 * (pts[idx] + pts[nxt])
+            rad = 0.5 * np.linalg.norm(pts[nxt] - pts[idx], axis=1)
+            out = []
+            for k in range(n_b):
+                present = (min(idx[k], nxt[k]), max(idx[k], nxt[k])) in edge_set
+                d = np.linalg.norm(pts - mids[k], axis=1)
+                d[[idx[k], nxt[k]]] = np.inf
+                encroached = bool((d < rad[k] * (1 - 1e-12)).any())
+                out.append(b[k])
+                if not present or encroached:
+                    out.append(mids[k])
+                    split = True
+            new_loops.append(np.array(out))
+            off += n_b
+        if not split:
+            break
+        bloops = new_loops
+        # lattice points too close to a refined boundary piece are dropped
+        ba = np.concatenate(bloops)
+        bb = np.concatenate([np.roll(b, -1, axis=0) for b in bloops])
+        seg_len = np.linalg.norm(bb - ba, axis=1)
+        short = seg_len < 0.5 * h
+        if short.any():
+            lattice = lattice[_segment_distance(lattice, ba[short], bb[short]) >= 0.6 * seg_len[short].max()]
+    else:  # pragma: no cover
+        raise RuntimeError("polygon_mesh: boundary did not become conforming")
+    used = np.unique(tri)
+    remap = np.full(len(pts), -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    return pts[used], remap[tri]

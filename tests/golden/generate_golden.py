@@ -283,6 +283,19 @@ def main():
     irregular = RefMesh.from_triangulation(pts, triangulate(pts))
     save("mesh_irregular", **mesh_arrays(irregular))
 
+    # a polygon with holes, meshed by the product's own mesher (the reference's shape of
+    # tdgl/test/conftest.py:7-49: 10x10 box united with a 30x4 strip, two round holes); the
+    # dual mesh is the REFERENCE's
+    from tdgl_amd.geometry import circle
+    from tdgl_amd.meshgen import polygon_mesh
+
+    film = np.array([(-15, -2), (-5, -2), (-5, -5), (5, -5), (5, -2), (15, -2), (15, 2), (5, 2), (5, 5),
+                     (-5, 5), (-5, 2), (-15, 2)], dtype=float)
+    holes = [circle(1.5, center=(-2.5, 0), points=40), circle(1.0, center=(2.5, 1.0), points=30)]
+    ppts, ptri = polygon_mesh(film, holes, max_edge_length=0.8)
+    save("mesh_polygon", film=film, hole0=holes[0], hole1=holes[1],
+         **mesh_arrays(RefMesh.from_triangulation(ppts, ptri)))
+
     # ---- (2) operators --------------------------------------------------------------
     A = uniform_field_A(small, 0.3)
     fixed = np.flatnonzero(np.isclose(small.sites[:, 0], -10.0))

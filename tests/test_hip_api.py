@@ -117,3 +117,32 @@ def test_time_dependent_field_through_the_public_api():
     # while the field changes, dA/dt drives a normal current: J_n != 0 early in the ramp
     early = solution.saved_steps[1]
     assert np.abs(early.normal_current).max() > 1e-6
+
+
+def test_device_with_holes_and_terminals_runs_and_conserves_current():
+    """The reference's transport_device shape (tdgl/test/conftest.py:7-49: 10x10 box united with a
+    30x4 strip, two round holes, source/drain terminals), meshed by the built-in polygon mesher."""
+    import tdgl_amd as tdgl
+    from conftest import load_golden
+
+    g = load_golden("mesh_polygon")
+    layer = tdgl.Layer(coherence_length=0.5, london_lambda=2.0, thickness=0.1)
+    device = tdgl.Device(
+        "transport", layer=layer, film=tdgl.Polygon("film", points=g["film"]),
+        holes=[tdgl.Polygon("h0", points=g["hole0"]), tdgl.Polygon("h1", points=g["hole1"])],
+        terminals=[tdgl.Polygon("source", points=[(-15.1, -2.1), (-14.9, -2.1), (-14.9, 2.1), (-15.1, 2.1)]),
+                   tdgl.Polygon("drain", points=[(14.9, -2.1), (15.1, -2.1), (15.1, 2.1), (14.9, 2.1)])],
+        probe_points=[(-10, 0), (10, 0)], length_units="um",
+    )
+    device.make_mesh(max_edge_length=0.25)
+    assert len(device.mesh.sites) > 5000
+    options = tdgl.SolverOptions(solve_time=10, dt_init=1e-3, field_units="uT", current_units="uA", save_every=100)
+    solution = tdgl.solve(device, options, applied_vector_potential=1.0, terminal_currents=dict(source=10.0, drain=-10.0))
+    j_scale = device.current_scale("uA")
+    xi = device.coherence_length
+    for x in (-12.03, -7.51, 7.49, 11.97):  # cuts through the strip arms
+        measured = solution.current_through_cut(x / xi) / j_scale * xi
+        assert np.isclose(measured, 10.0, rtol=1e-6), (x, measured)
+    # a cut through the box passes the holes: the current through the film is still I
+    assert np.isclose(solution.current_through_cut(0.013 / xi) / j_scale * xi, 10.0, rtol=1e-6)
+    assert np.abs(solution.tdgl_data.psi).max() < 1.2  # transient overshoot near phase slips is physical

@@ -166,8 +166,42 @@ def test_polygon_and_invalid_inputs():
         Device("d", layer=layer, film=sq, terminals=[Polygon("t", points=box(1)), Polygon("t", points=box(1))])
     with pytest.raises(ValueError, match="must lie within the film"):
         Device("d", layer=layer, film=sq, probe_points=[(5, 5), (0, 0)])
-    with pytest.raises(NotImplementedError):
-        Device("d", layer=layer, film=Polygon("c", points=circle(3.0))).make_mesh()
+
+
+def test_polygon_mesher_with_holes_is_boundary_conforming():
+    """The built-in mesher on the reference's transport-device shape (box + strip, two holes)."""
+    from tdgl_amd import Device, Layer, Polygon
+    from tdgl_amd.geometry import circle
+
+    g = load_golden("mesh_polygon")
+    layer = Layer(coherence_length=1.0, london_lambda=2.0, thickness=0.1)
+    dev = Device(
+        "transport", layer=layer, film=Polygon("film", points=g["film"]),
+        holes=[Polygon("h0", points=g["hole0"]), Polygon("h1", points=g["hole1"])],
+        terminals=[Polygon("source", points=[(-15.1, -2.1), (-14.9, -2.1), (-14.9, 2.1), (-15.1, 2.1)]),
+                   Polygon("drain", points=[(14.9, -2.1), (15.1, -2.1), (15.1, 2.1), (14.9, 2.1)])],
+        probe_points=[(-10, 0), (10, 0)],
+    )
+    dev.make_mesh(max_edge_length=0.8)
+    mesh = dev.mesh
+    # the same mesher call produced the fixture: identical points, and the reference's dual mesh
+    assert np.array_equal(mesh.sites, g["mesh_sites"]) and np.array_equal(mesh.elements, g["mesh_elements"])
+    assert max_abs(mesh.areas, g["mesh_areas"]) < 1e-13
+    em = mesh.edge_mesh
+    assert em.edge_lengths.max() <= 0.8
+    assert em.dual_edge_lengths.min() >= 0 and mesh.areas.min() > 0
+    # total area = polygon area minus holes (polygonal circles)
+    want = dev.film.area - sum(h.area for h in dev.holes)
+    assert np.isclose(mesh.areas.sum(), want, rtol=1e-12)
+    # Gabriel boundary: every boundary triangle's circumcentre is on the domain side, i.e. the
+    # boundary dual lengths computed as |cc - midpoint| equal the signed heights
+    info = dev.terminal_info()
+    assert sorted(t.name for t in info) == ["drain", "source"]
+    for t in info:
+        assert np.isclose(t.length, 4.0) and len(t.site_indices) >= 5
+    # no mesh point inside a hole, none outside the film
+    assert dev.contains_points(mesh.sites, radius=1e-9).all() or dev.contains_points(mesh.sites, radius=-1e-9).sum() > 0.9 * len(mesh.sites)
+    assert not Polygon("c", points=circle(1.4, center=(-2.5, 0))).contains_points(mesh.sites).any()
 
 
 # ---------------------------------------------------------------- reordering and AMG set-up

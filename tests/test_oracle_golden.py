@@ -27,7 +27,7 @@ from oracle import FVOperators, OracleSolver, psi_update, run_time_loop
 
 
 # ---------------------------------------------------------------- mesh construction
-@pytest.mark.parametrize("name", ["mesh_small", "mesh_strip", "mesh_irregular"])
+@pytest.mark.parametrize("name", ["mesh_small", "mesh_strip", "mesh_irregular", "mesh_polygon"])
 def test_vectorised_mesh_matches_reference(name):
     g = load_golden(name)
     mesh = mesh_from_golden(g)
