@@ -172,7 +172,8 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
-    tdgl::DevBuf<double> part_rz[2], part_pq, part_rr[2], part_tmp;  // NB per-workgroup partials each
+    tdgl::DevBuf<double> part_pair[2];    // 2 x NB partials each: [r.z | ||r||^2], ping-pong
+    tdgl::DevBuf<double> part_pq, part_tmp;  // NB per-workgroup partials each
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
     tdgl::DevBuf<double> mu_prev, mu_prev2;  // mu^{n-1}, mu^{n-2} for the extrapolated initial guess
     double prev_dt = 0.0, prev_dt2 = 0.0;    // dt of the steps that produced mu / mu_prev (0: no history)
