@@ -39,6 +39,11 @@ WORKLOADS = {
 }
 B_FIELD = 0.1  # B / Bc2
 
+# HBM bytes per launch of the fused psi-Laplacian kernel from rocprofv3 PMC counters
+# ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction calibrated on a copy kernel in the same
+# run: profiles/r01_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
+PMC_TRAFFIC_BYTES = {"1M": 192.4e6}
+
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
@@ -255,7 +260,8 @@ def main():
         peak=HBM_PEAK_GBS,
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 4),
-        traffic=None,
+        traffic=PMC_TRAFFIC_BYTES.get(args.workload) if not use_dd else None,
+        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_hbm_traffic_1M.txt",
         algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"],
         avg_launch_ms=round(k1_avg_ms, 5),
         launches=launches,

@@ -12,13 +12,8 @@ def rotate(coords: np.ndarray, angle_degrees: float) -> np.ndarray:
     return np.asarray(coords) @ rot.T
 
 
-def box(
-    width: float,
-    height: Optional[float] = None,
-    points: int = 101,
-    center: Tuple[float, float] = (0, 0),
-    angle: float = 0,
-) -> np.ndarray:
+def box(width: float, height: Optional[float] = None, points: int = 101,
+        center: Tuple[float, float] = (0, 0), angle: float = 0) -> np.ndarray:
     """Boundary points of a ``width x height`` rectangle, counter-clockwise from the
     lower-right corner, about ``points`` of them, centred on ``center``."""
     width = abs(width)

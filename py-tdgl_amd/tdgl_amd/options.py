@@ -34,30 +34,30 @@ class SparseSolver(Enum):
 
 @dataclass
 class SolverOptions:
-    solve_time: float
-    skip_time: float = 0.0
-    dt_init: float = 1e-6
-    dt_max: float = 1e-1
-    adaptive: bool = True
-    adaptive_window: int = 10
-    max_solve_retries: int = 10
-    adaptive_time_step_multiplier: float = 0.25
-    output_file: Union[str, None] = None
-    terminal_psi: Union[float, complex, None] = 0.0
-    gpu: bool = False
-    sparse_solver: Union[SparseSolver, str] = SparseSolver.SUPERLU
-    pause_on_interrupt: bool = True
-    save_every: int = 100
-    progress_interval: int = 0
-    monitor: bool = False
-    monitor_update_interval: float = 1.0
-    field_units: str = "mT"
-    current_units: str = "uA"
-    include_screening: bool = False
-    max_iterations_per_step: int = 1000
-    screening_tolerance: float = 1e-3
-    screening_step_size: float = 0.1
-    screening_step_drag: float = 0.5
+    solve_time: float  # simulated time after thermalisation, in units of tau_0
+    skip_time: float = 0.0  # thermalisation time simulated first, not recorded
+    dt_init: float = 1e-6  # first (and, if not adaptive, only) time step
+    dt_max: float = 1e-1  # cap of the adaptive time step
+    adaptive: bool = True  # adapt dt to the rate of change of |psi|^2
+    adaptive_window: int = 10  # number of recent steps averaged by the dt controller
+    max_solve_retries: int = 10  # dt reductions allowed within one step
+    adaptive_time_step_multiplier: float = 0.25  # dt factor per retry, in (0, 1)
+    output_file: Union[str, None] = None  # accepted, unused (results stay in memory)
+    terminal_psi: Union[float, complex, None] = 0.0  # psi pinned on terminal sites; None = free
+    gpu: bool = False  # accepted, no effect: the HIP path is the only path
+    sparse_solver: Union[SparseSolver, str] = SparseSolver.SUPERLU  # any value -> AMG-PCG
+    pause_on_interrupt: bool = True  # accepted, unused
+    save_every: int = 100  # steps between saved snapshots
+    progress_interval: int = 0  # accepted, unused
+    monitor: bool = False  # accepted, unused (no live viewer)
+    monitor_update_interval: float = 1.0  # accepted, unused
+    field_units: str = "mT"  # units of applied fields
+    current_units: str = "uA"  # units of terminal currents
+    include_screening: bool = False  # True is rejected by validate()
+    max_iterations_per_step: int = 1000  # screening only
+    screening_tolerance: float = 1e-3  # screening only
+    screening_step_size: float = 0.1  # screening only
+    screening_step_drag: float = 0.5  # screening only
     # --- native Poisson-solve controls (no reference counterpart) ---
     pcg_rtol: float = 1e-10
     pcg_max_iter: int = 500
