@@ -80,12 +80,25 @@ class OracleSolver:
         probe_points=None,
         vector_potential_func=None,
         epsilon_func=None,
+        screening=None,
     ):
-        """``vector_potential_func(t) -> A[m, 2]`` / ``epsilon_func(t) -> eps[n]`` (both already
+        """``screening``: ``None`` or a dict ``{areas, sites, edge_centers, tolerance,
+        max_iterations, step_size, step_drag}`` (the arrays of solver.py:306-314, i.e. areas
+        already multiplied by the screening scale) -- switches on the self-consistent induced
+        vector potential (solver.py:522-578, 654-688).
+
+        ``vector_potential_func(t) -> A[m, 2]`` / ``epsilon_func(t) -> eps[n]`` (both already
         dimensionless) switch on the reference's time-dependent branches (solver.py:626-648)."""
         self.mesh = mesh
         self.vector_potential_func = vector_potential_func
         self.epsilon_func = epsilon_func
+        self.screening = screening
+        if screening is not None:
+            d = screening["edge_centers"][:, None, :] - screening["sites"][None, :, :]
+            # K[i, j] = area_j / |r_edge_i - r_site_j|   (tdgl/solver/screening.py:12-42)
+            self._inv_r_area = screening["areas"][None, :] / np.sqrt((d**2).sum(axis=2))
+            self.A_induced = np.zeros_like(np.asarray(link_exponents, dtype=float))
+            self.last_screening_iterations = 0
         self.current_A = np.asarray(link_exponents, dtype=float)
         self.edge_unit = mesh.edge_mesh.directions / np.linalg.norm(
             mesh.edge_mesh.directions, axis=1)[:, None]
@@ -184,6 +197,52 @@ class OracleSolver:
             self.epsilon = np.asarray(self.epsilon_func(time), dtype=float)
         return dA_dt
 
+    def _site_average(self, edge_field):
+        """`Mesh.get_quantity_on_site` (tdgl/finite_volume/mesh.py:203-243): mean over the
+        incident edges of F_e * e_hat, divided by 2."""
+        edges = self.mesh.edge_mesh.edges
+        n = len(self.mesh.sites)
+        verts = np.concatenate([edges[:, 0], edges[:, 1]])
+        counts = np.bincount(verts, minlength=n)
+        out = np.empty((n, 2))
+        for k in range(2):
+            flux = edge_field * self.edge_unit[:, k]
+            out[:, k] = np.bincount(verts, weights=np.concatenate([flux, flux]), minlength=n) / counts / 2
+        return out
+
+    def _update_with_screening(self, step, psi, mu, old_sq, dA_dt):
+        """The screening loop of solver.py:654-688.  Faithful to the reference, including that
+        psi / mu / dt carry over from one screening iteration to the next while |psi|^2 in the
+        update formula stays that of the step's starting psi."""
+        sc = self.screening
+        alpha, beta = sc["step_size"], sc["step_drag"]
+        A_ind, velocity = self.A_induced, 0.0
+        error = np.inf
+        dt = self.tentative_dt
+        for it in itertools.count():
+            if error < sc["tolerance"]:
+                break
+            if it > sc["max_iterations"]:
+                raise RuntimeError(
+                    f"Screening calculation failed to converge at step {step} after"
+                    f" {sc['max_iterations']} iterations. Relative error in"
+                    f" induced vector potential: {error:.2e}"
+                    f" (tolerance: {sc['tolerance']:.2e})."
+                )
+            self.operators.set_link_exponents(self.current_A + A_ind)
+            psi, new_sq, dt = self._euler_step(step, psi, old_sq, mu, dt)
+            mu, js, jn = self._observables(psi, dA_dt)
+            # solver.py:522-578: Polyak (heavy-ball) update of the induced vector potential
+            new_A = self._inv_r_area @ self._site_average(js + jn)
+            dA = new_A - A_ind
+            velocity = (1 - beta) * velocity + alpha * dA
+            A_ind = A_ind + velocity
+            denom = np.maximum(np.linalg.norm(A_ind, axis=1), 1e-20)
+            error = float(np.max(np.linalg.norm(dA, axis=1) / denom))
+        self.A_induced = A_ind
+        self.last_screening_iterations = it
+        return psi, new_sq, dt, mu, js, jn
+
     # -- one step ---------------------------------------------------------------------
     def update(self, state, running_state, dt, *, psi, mu, **_unused):
         """solver.py:580-714 without screening.
@@ -196,11 +255,16 @@ class OracleSolver:
         self._set_terminal_bc(time)
         dA_dt = self._update_dynamic_inputs(time, dt)
         old_sq = np.absolute(psi) ** 2
-        dt = self.tentative_dt
-        psi, new_sq, dt = self._euler_step(step, psi, old_sq, mu, dt)
-        mu, js, jn = self._observables(psi, dA_dt)
+        if self.screening is not None:
+            psi, new_sq, dt, mu, js, jn = self._update_with_screening(step, psi, mu, old_sq, dA_dt)
+        else:
+            dt = self.tentative_dt
+            psi, new_sq, dt = self._euler_step(step, psi, old_sq, mu, dt)
+            mu, js, jn = self._observables(psi, dA_dt)
         if running_state is not None:
             running_state.append("dt", dt)
+            if self.screening is not None:
+                running_state.append("screening_iterations", self.last_screening_iterations)
             if self.probe_points is not None:
                 running_state.append("mu", mu[self.probe_points])
                 running_state.append("theta", np.angle(psi[self.probe_points]))

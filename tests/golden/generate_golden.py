@@ -172,6 +172,8 @@ def run_reference(solver, psi0, options, snapshot_steps=()):
     def logged_update(state, running_state, dt, **values):
         result = solver.update(state, running_state, dt, **values)
         rec = dict(stage_step=state["step"], time=state["time"], state_dt=state["dt"], dt=result[0])
+        if solver.options.include_screening:
+            rec["screening_iterations"] = int(running_state.values["screening_iterations"][0, running_state.step])
         if solver.probe_points is not None:
             rec["mu_probe"] = np.array(result[2][solver.probe_points])
             rec["theta_probe"] = np.angle(result[1][solver.probe_points])
@@ -185,6 +187,8 @@ def run_reference(solver, psi0, options, snapshot_steps=()):
     if solver.probe_points is not None:
         sizes["mu"] = len(solver.probe_points)
         sizes["theta"] = len(solver.probe_points)
+    if solver.options.include_screening:
+        sizes["screening_iterations"] = 1
     handler = MemoryHandler()
     runner = Runner(
         function=logged_update,
@@ -199,7 +203,9 @@ def run_reference(solver, psi0, options, snapshot_steps=()):
     ok = runner.run()
     assert ok
     psi, mu, js, jn = runner.values[:4]
+    a_ind = runner.values[4]
     out = dict(
+        final_A_induced=np.asarray(a_ind),
         final_psi=psi,
         final_mu=mu,
         final_supercurrent=js,
@@ -215,6 +221,8 @@ def run_reference(solver, psi0, options, snapshot_steps=()):
         final_runner_time=float(runner.time),
         d_psi_sq_vals=np.array(solver.d_psi_sq_vals),
     )
+    if solver.options.include_screening:
+        out["call_screening_iterations"] = np.array([c["screening_iterations"] for c in calls])
     if solver.probe_points is not None:
         out["call_mu_probe"] = np.array([c["mu_probe"] for c in calls])
         out["call_theta_probe"] = np.array([c["theta_probe"] for c in calls])
@@ -442,6 +450,31 @@ def main():
     print("dynamic calls:", len(out["call_dt"]), "min|psi|^2", (np.abs(out["final_psi"]) ** 2).min())
     save("traj_dynamic_small", b_final=0.6, probe_points=np.array(probes), A_full=A_full,
          **options_arrays(o), **out)
+
+    # (4h) screening (solver.py:522-578, 654-688; tdgl/solver/screening.py:12-42): the induced
+    # vector potential is iterated to self-consistency inside every step.  Tiny mesh: without
+    # numba the reference's 1/r double loop is pure Python.
+    tiny = make_ref_mesh(12, 9)
+    o = SolverOptions(solve_time=1.5, dt_init=1e-3, save_every=100, include_screening=True,
+                      screening_tolerance=1e-3, max_iterations_per_step=400)
+    probes = [tiny.closest_site((-3, 0)), tiny.closest_site((3, 0))]
+    A_tiny = uniform_field_A(tiny, 0.4)
+    s, psi0, _ = make_ref_solver(tiny, A_tiny, o, probe_points=probes)
+    from types import SimpleNamespace
+
+    s.device = SimpleNamespace(mesh=tiny)
+    screening_scale = 0.05  # stands for (mu_0 / 4 pi) K0 / A0 * xi^2 (solver.py:307-309)
+    s.areas = screening_scale * tiny.areas
+    s.sites = tiny.sites
+    s.edge_centers = tiny.edge_mesh.centers
+    s.num_edges = len(tiny.edge_mesh.edges)
+    s.new_A_induced = np.empty((s.num_edges, 2))
+    out = run_reference(s, psi0, o, snapshot_steps=(0, 5))
+    print("screening calls:", len(out["call_dt"]), "max |A_ind|", np.abs(out["final_A_induced"]).max())
+    save("traj_screening_tiny", b=0.4, screening_scale=screening_scale, probe_points=np.array(probes),
+         **mesh_arrays(tiny), **options_arrays(o),
+         opt_screening_tolerance=o.screening_tolerance, opt_max_iterations_per_step=o.max_iterations_per_step,
+         opt_screening_step_size=o.screening_step_size, opt_screening_step_drag=o.screening_step_drag, **out)
 
     # ---- (5) runner bookkeeping: thermalise + save_every not dividing the step count ----
     o = SolverOptions(solve_time=1.0, skip_time=0.5, dt_init=1e-3, save_every=7)

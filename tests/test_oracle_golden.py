@@ -218,6 +218,29 @@ def _hot_spot(r, t):
     return 1.0 - 0.6 * np.exp(-((r - c) ** 2).sum(axis=1) / 4.0)
 
 
+def _screening_dict(g, mesh):
+    return dict(
+        areas=float(g["screening_scale"]) * mesh.areas, sites=mesh.sites, edge_centers=mesh.edge_mesh.centers,
+        tolerance=float(g["opt_screening_tolerance"]), max_iterations=int(g["opt_max_iterations_per_step"]),
+        step_size=float(g["opt_screening_step_size"]), step_drag=float(g["opt_screening_step_drag"]),
+    )
+
+
+def test_trajectory_with_screening():
+    g = load_golden("traj_screening_tiny")
+    mesh = reference_mesh(g)
+    opts = options_from_golden(g)
+    solver = OracleSolver(
+        mesh, uniform_field_A(mesh, float(g["b"])), 1.0, U_DEFAULT, GAMMA_DEFAULT, opts,
+        probe_points=[int(p) for p in g["probe_points"]], screening=_screening_dict(g, mesh),
+    )
+    out = run_time_loop(solver, opts)
+    # the oracle sums the 1/r kernel as a matrix product, the reference in a sequential loop
+    _assert_trajectory(g, mesh, out, 1e-10)
+    assert np.array_equal(out["log"].array("screening_iterations").astype(int), g["call_screening_iterations"])
+    assert max_abs(solver.A_induced, g["final_A_induced"]) < 1e-12
+
+
 def test_trajectory_with_dt_retries():
     g = load_golden("traj_retry_small")
     mesh = reference_mesh(load_golden("mesh_small"))
