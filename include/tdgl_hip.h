@@ -36,7 +36,9 @@ typedef enum {
     TDGL_ERR_PSI_RETRIES = 3,  /* psi update failed after max_solve_retries (reference:
                                   RuntimeError at tdgl/solver/solver.py:478-483) */
     TDGL_ERR_PCG = 4,          /* Poisson solve did not reach the tolerance */
-    TDGL_ERR_NOT_READY = 5     /* hierarchy / link variables / state not set yet */
+    TDGL_ERR_NOT_READY = 5,    /* hierarchy / link variables / state not set yet */
+    TDGL_ERR_SCREENING = 6     /* screening iteration did not converge (reference: RuntimeError
+                                  at tdgl/solver/solver.py:657-663) */
 } tdgl_status;
 
 /* Mesh description: the arrays of the reference's Mesh/EdgeMesh plus the boundary
@@ -179,6 +181,26 @@ int tdgl_set_controller(tdgl_ctx *ctx, const tdgl_controller *c);
 /* Probe sites (device.probe_point_indices, solver.py:142, 691-694); n_probe may be 0. */
 int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_probe);
 
+/* ------------------------------------------------------------------ screening
+ * options.include_screening (solver.py:304-314, 522-578, 654-688; kernel: tdgl/solver/screening.py).
+ * Inside every step the induced vector potential A_ind[e] = sum_j K_site[j] area_j / |r_e - r_j|
+ * is iterated to self-consistency with Polyak's heavy-ball update; the link variables use
+ * A_applied + A_induced.  sites_xy [n,2] / edge_centers_xy [m,2] are the dimensionful positions
+ * and site_areas [n] the areas already multiplied by the screening scale, exactly the arrays the
+ * reference passes to its kernel (solver.py:307-313).  opts == NULL switches screening off.
+ * Not available in one-process-per-GPU mode. */
+typedef struct {
+    int32_t max_iterations;   /* SolverOptions.max_iterations_per_step */
+    double tolerance;         /* SolverOptions.screening_tolerance      */
+    double step_size;         /* SolverOptions.screening_step_size (alpha) */
+    double step_drag;         /* SolverOptions.screening_step_drag (beta)  */
+} tdgl_screening_options;
+int tdgl_set_screening(tdgl_ctx *ctx, const tdgl_screening_options *opts, const double *sites_xy,
+                       const double *edge_centers_xy, const double *site_areas);
+/* A_induced [n_edges, 2] in reference edge order (seed / read-out; solver.py:738, 751). */
+int tdgl_set_induced_vector_potential(tdgl_ctx *ctx, const double *A_induced);
+int tdgl_get_induced_vector_potential(tdgl_ctx *ctx, double *A_induced);
+
 /* ------------------------------------------------------------------ the time loop */
 /* Start a Runner stage (runner.py:294-297, 315-318): time = 0, stage step = 0.  Runner.dt
  * and the controller state are deliberately NOT reset. */
@@ -192,12 +214,14 @@ int tdgl_begin_stage(tdgl_ctx *ctx);
  *   out_mu_probe         mu at the probe sites        [max_steps, n_probe] (may be NULL)
  *   out_theta_probe      arg(psi) at the probe sites  [max_steps, n_probe] (may be NULL)
  *   out_pcg_iters[k]     Poisson iterations used                          (may be NULL)
+ *   out_screening_iters[k]  screening iterations of step k (running_state
+ *                        "screening_iterations", solver.py:695-696)       (may be NULL)
  *   steps_done           iterations executed
  *   reached_end          1 if the loop ended because time >= end_time
  * Returns TDGL_ERR_PSI_RETRIES with the reference's message when the psi update fails. */
 int tdgl_run(tdgl_ctx *ctx, int64_t max_steps, double end_time, double *out_dt,
              double *out_mu_probe, double *out_theta_probe, int32_t *out_pcg_iters,
-             int64_t *steps_done, int32_t *reached_end);
+             int64_t *steps_done, int32_t *reached_end, int32_t *out_screening_iters);
 
 /* Loop state: stage step index i, Runner.time, Runner.dt (state["dt"] of the next
  * iteration), tentative_dt of the controller. */

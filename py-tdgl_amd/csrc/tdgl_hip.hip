@@ -390,10 +390,10 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
 }
 
 static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
-                              double dt, double2 *psi_new, double *abs_sq) {
+                              double dt, double2 *psi_new, double *abs_sq, const double *abs_sq_in = nullptr) {
     const int grid = std::min<int64_t>(grid_for(ctx->n_own), 2048);
     hipLaunchKernelGGL(k_psi_update, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->n_own, psi, mu,
-                       ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p);
+                       ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p, abs_sq_in);
 }
 
 static void launch_edge_currents(tdgl_ctx *ctx, const double2 *psi, const double *mu, double *js,
@@ -422,6 +422,7 @@ static void refresh_ceff(tdgl_ctx *ctx) {
 
 #include "comm.inc"
 #include "poisson.inc"
+#include "screening.inc"
 #include "run.inc"
 
 // ---------------------------------------------------------------------------------------
@@ -457,7 +458,8 @@ static int set_links_impl(tdgl_ctx *ctx, const double *A, bool dynamic, double d
     }
     refresh_ceff(ctx);
     hipLaunchKernelGGL(k_link_variables, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                       ctx->e_A.p, ctx->e_dirx.p, ctx->e_diry.p, ctx->e_U.p);
+                       ctx->e_A.p, ctx->scr_enabled ? ctx->scr_Aind.p : (const double *)nullptr, ctx->e_dirx.p,
+                       ctx->e_diry.p, ctx->e_U.p);
     hipLaunchKernelGGL(k_fill_laplacian, dim3(grid_for(ctx->lap_pat.n_slots)), dim3(BLOCK), 0, ctx->stream,
                        ctx->lap_pat.n_slots, ctx->lap_slot_edge.p, ctx->lap_slot_w.p, ctx->e_U.p, ctx->lap_vals.p);
     HIP_TRY(ctx, hipGetLastError());

@@ -196,6 +196,18 @@ struct tdgl_ctx {
     double runner_dt = 1e-6, time = 0.0;
     int64_t stage_step = 0;
 
+    // ---- screening (screening.inc) -------------------------------------------------------
+    bool scr_enabled = false;
+    tdgl_screening_options scr{1000, 1e-3, 0.1, 0.5};
+    tdgl::DevBuf<double> scr_site_xyw;   // per site: x, y, scaled area  [3 * n_pad]
+    tdgl::DevBuf<double> scr_edge_xy;    // per edge (internal order): x, y  [2 * m_pad]
+    tdgl::DevBuf<double> scr_inv_2deg;   // 1 / (2 * number of incident edges)  [n_pad]
+    tdgl::DevBuf<double> scr_Jsite;      // site-averaged K = J_s + J_n  [2 * n_pad]
+    tdgl::DevBuf<double> scr_Aind, scr_vel, scr_Anew;  // [2 * m_pad], internal edge order
+    tdgl::DevBuf<double> abs_sq_old;     // |psi^n|^2 of the step's starting psi [n_pad]
+    tdgl::DevBuf<unsigned long long> scr_err_bits;
+    int32_t last_screening_iters = 0;
+
     // ---- measurement -------------------------------------------------------------------
     bool profile = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -107,6 +107,15 @@ class PoissonOptions(C.Structure):
     ]
 
 
+class ScreeningOptions(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32),
+        ("tolerance", C.c_double),
+        ("step_size", C.c_double),
+        ("step_drag", C.c_double),
+    ]
+
+
 # name -> (restype, argtypes); also the list of symbols the header declares
 _CTX = C.c_void_p
 SIGNATURES = {
@@ -133,8 +142,13 @@ SIGNATURES = {
     "tdgl_run": (
         C.c_int,
         [_CTX, C.c_int64, C.c_double, c_f64p, c_f64p, c_f64p, c_i32p,
-         C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
+         C.POINTER(C.c_int64), C.POINTER(C.c_int32), c_i32p],
     ),
+    "tdgl_set_screening": (
+        C.c_int, [_CTX, C.POINTER(ScreeningOptions), c_f64p, c_f64p, c_f64p]
+    ),
+    "tdgl_set_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_get_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
     "tdgl_get_loop_state": (
         C.c_int,
         [_CTX, C.POINTER(C.c_int64), c_f64p, c_f64p, c_f64p],

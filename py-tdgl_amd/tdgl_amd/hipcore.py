@@ -280,18 +280,46 @@ class TDGLContext:
         mu_p = np.zeros((max_steps, npb)) if npb else None
         th_p = np.zeros((max_steps, npb)) if npb else None
         iters = np.zeros(max_steps, dtype=np.int32)
+        scr_iters = np.zeros(max_steps, dtype=np.int32)
         done, reached = C.c_int64(0), C.c_int32(0)
         status = self._lib.tdgl_run(
             self._ctx, max_steps, float(end_time), p_f64(dts), p_f64(mu_p), p_f64(th_p),
-            p_i32(iters), C.byref(done), C.byref(reached),
+            p_i32(iters), C.byref(done), C.byref(reached), p_i32(scr_iters),
         )
         self._chk(status)
         k = done.value
         return dict(
             dt=dts[:k], mu=None if mu_p is None else mu_p[:k],
             theta=None if th_p is None else th_p[:k], pcg_iters=iters[:k],
-            reached_end=bool(reached.value),
+            screening_iterations=scr_iters[:k], reached_end=bool(reached.value),
         )
+
+    # -- screening (solver.py:522-578, 654-688) -----------------------------------------------
+    def set_screening(self, sites, edge_centers, areas, max_iterations=1000, tolerance=1e-3,
+                      step_size=0.1, step_drag=0.5):
+        """Enable the self-consistent induced vector potential.  ``sites`` / ``edge_centers`` are
+        coordinates in the length unit of the 1/r kernel and ``areas`` the site areas already
+        multiplied by the kernel's prefactor (so that A_induced comes out in units of the applied
+        link exponents).  ``None`` for ``sites`` disables screening."""
+        if sites is None:
+            self._chk(self._lib.tdgl_set_screening(self._ctx, None, None, None, None))
+            return
+        opts = _lib.ScreeningOptions(int(max_iterations), float(tolerance), float(step_size), float(step_drag))
+        sites, edge_centers, areas = f64(sites), f64(edge_centers), f64(areas)
+        if sites.shape != (self.n, 2) or edge_centers.shape != (self.m, 2) or areas.shape != (self.n,):
+            raise ValueError("set_screening: sites (n, 2), edge_centers (m, 2), areas (n,) expected")
+        self._chk(self._lib.tdgl_set_screening(self._ctx, C.byref(opts), p_f64(sites), p_f64(edge_centers), p_f64(areas)))
+
+    def set_induced_vector_potential(self, A):
+        A = f64(A)
+        if A.shape != (self.m, 2):
+            raise ValueError("A_induced must have shape (n_edges, 2)")
+        self._chk(self._lib.tdgl_set_induced_vector_potential(self._ctx, p_f64(A)))
+
+    def induced_vector_potential(self):
+        A = np.empty((self.m, 2))
+        self._chk(self._lib.tdgl_get_induced_vector_potential(self._ctx, p_f64(A)))
+        return A
 
     def loop_state(self):
         step, t, rdt, tdt = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)

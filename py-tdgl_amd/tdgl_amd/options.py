@@ -53,7 +53,7 @@ class SolverOptions:
     monitor_update_interval: float = 1.0  # accepted, unused
     field_units: str = "mT"  # units of applied fields
     current_units: str = "uA"  # units of terminal currents
-    include_screening: bool = False  # True is rejected by validate()
+    include_screening: bool = False
     max_iterations_per_step: int = 1000  # screening only
     screening_tolerance: float = 1e-3  # screening only
     screening_step_size: float = 0.1  # screening only
@@ -93,11 +93,8 @@ class SolverOptions:
             self.sparse_solver = solver
         if not isinstance(self.sparse_solver, SparseSolver):
             fail(f"sparse solver must be a SparseSolver or str, got {self.sparse_solver!r}.")
-        if self.include_screening:
-            fail(
-                "include_screening=True is not supported by the MI355X time-stepping core"
-                " (the reference's dense 1/r kernel, tdgl/solver/screening.py, is out of scope)."
-            )
+        if self.include_screening and self.max_iterations_per_step < 1:
+            fail("max_iterations_per_step must be >= 1.")
         if not (self.pcg_rtol > 0):
             fail(f"pcg_rtol must be > 0 (got {self.pcg_rtol}).")
         if self.pcg_max_iter < 1 or self.amg_smoothing_sweeps < 1:

@@ -25,6 +25,7 @@ class TDGLData:
     normal_current: np.ndarray
     applied_vector_potential: Optional[np.ndarray] = None
     epsilon: Optional[np.ndarray] = None
+    induced_vector_potential: Optional[np.ndarray] = None  # include_screening only
 
 
 @dataclass
@@ -36,6 +37,7 @@ class DynamicsData:
     mu: Optional[np.ndarray] = None      # [n_probe, n_steps]
     theta: Optional[np.ndarray] = None   # [n_probe, n_steps]
     pcg_iterations: Optional[np.ndarray] = None
+    screening_iterations: Optional[np.ndarray] = None  # include_screening only
 
     def voltage(self, i: int = 0, j: int = 1) -> np.ndarray:
         """mu_i - mu_j between two probe points, per step."""

@@ -14,7 +14,9 @@ What runs where:
 Time-dependent ``applied_vector_potential`` (a ``Parameter`` with a keyword-only ``t``) and
 ``disorder_epsilon`` are evaluated in Python once per step and uploaded; dA/dt and the link
 variables are then formed on the device (``tdgl_update_link_exponents``).
-Not supported (raise): ``include_screening``, HDF5 output.
+``include_screening`` runs the reference's self-consistent loop for the induced vector
+potential (solver.py:522-578, 654-688) entirely on the device; Python only hands over the site /
+edge coordinates and the scaled site areas (solver.py:305-309).  Not supported: HDF5 output.
 """
 
 import inspect
@@ -180,18 +182,30 @@ class TDGLSolver:
         J_scale = device.current_scale(options.current_units)
         self.current_func = lambda t: {k: J_scale * v for k, v in raw_func(t).items()}
         validate_terminal_currents(self.current_func, self.terminal_info, options)
+        # ---- screening (solver.py:305-309) ------------------------------------------------------
+        # (mu_0 / 4 pi) K0 / A0 = 1 / (pi Lambda): converts the 1/r integral of the sheet
+        # current (units of K0) into a vector potential in units of A0 = xi Bc2.
+        self.screening = None
+        if options.include_screening:
+            a_scale = 1.0 / (np.pi * device.Lambda)
+            self.screening = dict(
+                sites=self.sites, edge_centers=self.edge_centers, areas=a_scale * mesh.areas * xi**2
+            )
         self._setup(mesh)
 
     @classmethod
     def from_dimensionless(cls, mesh, options: SolverOptions, link_exponents, epsilon=1.0,
                            u: float = 5.79, gamma: float = 10.0, terminal_info=(),
                            current_func=None, probe_points=None, device=None,
-                           vector_potential_func=None, epsilon_func=None) -> "TDGLSolver":
+                           vector_potential_func=None, epsilon_func=None,
+                           screening=None) -> "TDGLSolver":
         """Build a solver directly from dimensionless inputs -- the arrays the reference's
         ``__init__`` ends up with (solver.py:185, 214, 225, 254-256): ``A[m, 2]``,
         ``epsilon[n]``, ``TerminalInfo`` records and ``t -> {name: dimensionless current}``.
         Used by the parity tests and the benchmark, whose configurations are stated in
-        dimensionless form (b = B/Bc2, xi = 1)."""
+        dimensionless form (b = B/Bc2, xi = 1).  ``screening``: ``{sites, edge_centers, areas}``
+        (areas already multiplied by the kernel prefactor, solver.py:307-309); requires
+        ``options.include_screening``."""
         self = object.__new__(cls)
         options.validate()
         self.device = device
@@ -228,6 +242,9 @@ class TDGLSolver:
             current_func = lambda t: const  # noqa: E731
         self.current_func = current_func
         validate_terminal_currents(self.current_func, self.terminal_info, options)
+        if options.include_screening and screening is None:
+            raise ValueError("include_screening=True needs the screening geometry (sites, edge_centers, areas).")
+        self.screening = dict(screening) if options.include_screening else None
         self._setup(mesh)
         return self
 
@@ -272,6 +289,12 @@ class TDGLSolver:
             options.dt_init, options.dt_max, options.adaptive, options.adaptive_window,
             options.max_solve_retries, options.adaptive_time_step_multiplier,
         )
+        if self.screening is not None:
+            self.ctx.set_screening(
+                self.screening["sites"], self.screening["edge_centers"], self.screening["areas"],
+                max_iterations=options.max_iterations_per_step, tolerance=options.screening_tolerance,
+                step_size=options.screening_step_size, step_drag=options.screening_step_drag,
+            )
         self._device_holds = None  # (psi, mu) arrays known to equal the device state
 
     # -- boundary conditions --------------------------------------------------------------------
@@ -319,18 +342,23 @@ class TDGLSolver:
         ctx.set_loop_state(state["step"], state["time"], state.get("dt", dt))
         self.update_mu_boundary(state["time"])
         self.update_dynamic_inputs(state["time"], dt)
+        if self.screening is not None and induced_vector_potential is not None:
+            ctx.set_induced_vector_potential(induced_vector_potential)
         res = ctx.run(1, np.inf)
         out = ctx.get_state()
         self._device_holds = (out["psi"], out["mu"])
         step_dt = float(res["dt"][0])
         if running_state is not None:
             running_state.append("dt", step_dt)
+            if self.screening is not None:
+                running_state.append("screening_iterations", int(res["screening_iterations"][0]))
             if self.probe_points is not None:
                 running_state.append("mu", res["mu"][0])
                 running_state.append("theta", res["theta"][0])
-        a_ind = (
-            np.zeros((self.num_edges, 2)) if induced_vector_potential is None else induced_vector_potential
-        )
+        if self.screening is not None:
+            a_ind = ctx.induced_vector_potential()
+        else:
+            a_ind = np.zeros((self.num_edges, 2)) if induced_vector_potential is None else induced_vector_potential
         extra = []
         if self.dynamic_vector_potential:
             extra.append(self.current_A_applied)
@@ -354,12 +382,15 @@ class TDGLSolver:
             seed = self.seed_solution.tdgl_data
             psi0, mu0 = seed.psi, seed.mu
         ctx.set_state(psi0, mu0)
+        if self.screening is not None:  # solver.py:738-745
+            a0 = None if self.seed_solution is None else self.seed_solution.tdgl_data.induced_vector_potential
+            ctx.set_induced_vector_potential(np.zeros((self.num_edges, 2)) if a0 is None else a0)
         ctx.set_controller(
             opts.dt_init, opts.dt_max, opts.adaptive, opts.adaptive_window,
             opts.max_solve_retries, opts.adaptive_time_step_multiplier,
         )
         saved = []
-        dyn = dict(dt=[], time=[], mu=[], theta=[], iters=[])
+        dyn = dict(dt=[], time=[], mu=[], theta=[], iters=[], scr=[])
         n_steps = {"Thermalizing": 0, "Simulating": 0}
 
         def save_step():
@@ -370,8 +401,10 @@ class TDGLSolver:
             else:
                 st = ctx.get_state()
                 js, jn = st["supercurrent"], st["normal_current"]
+            a_ind = ctx.induced_vector_potential() if self.screening is not None else None
             saved.append(TDGLData(ls["step"], ls["time"], ls["dt"], st["psi"], st["mu"], js, jn,
-                                  applied_vector_potential=self.current_A_applied, epsilon=self.epsilon))
+                                  applied_vector_potential=self.current_A_applied, epsilon=self.epsilon,
+                                  induced_vector_potential=a_ind))
 
         def run_stage(name, end_time, save):
             ctx.begin_stage()
@@ -393,6 +426,7 @@ class TDGLSolver:
                     times = t_before + np.concatenate([[0.0], np.cumsum(res["dt"][:-1])])
                     dyn["time"].append(times)
                     dyn["iters"].append(res["pcg_iters"])
+                    dyn["scr"].append(res["screening_iterations"])
                     if res["mu"] is not None:
                         dyn["mu"].append(res["mu"])
                         dyn["theta"].append(res["theta"])
@@ -415,6 +449,7 @@ class TDGLSolver:
             mu=cat(dyn["mu"]).T if dyn["mu"] else None,
             theta=cat(dyn["theta"]).T if dyn["theta"] else None,
             pcg_iterations=cat(dyn["iters"]),
+            screening_iterations=cat(dyn["scr"]) if self.screening is not None else None,
         )
         return Solution(
             device=self.device,

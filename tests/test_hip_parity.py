@@ -297,6 +297,46 @@ def test_trajectory_time_dependent_field_and_epsilon():
     _assert_hip_trajectory(g, sol, 1e-7)  # 265 steps; measured 1e-8
 
 
+def _screening_solver(g, mesh, **opt_override):
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    o = options_from_golden(g)
+    kw = dict(
+        solve_time=o.solve_time, dt_init=o.dt_init, dt_max=o.dt_max, save_every=o.save_every, pcg_rtol=1e-12,
+        include_screening=True, screening_tolerance=float(g["opt_screening_tolerance"]),
+        max_iterations_per_step=int(g["opt_max_iterations_per_step"]),
+        screening_step_size=float(g["opt_screening_step_size"]),
+        screening_step_drag=float(g["opt_screening_step_drag"]),
+    )
+    kw.update(opt_override)
+    return TDGLSolver.from_dimensionless(
+        mesh, SolverOptions(**kw), uniform_field_A(mesh, float(g["b"])), 1.0, U_DEFAULT, GAMMA_DEFAULT,
+        probe_points=[int(p) for p in g["probe_points"]],
+        screening=dict(sites=mesh.sites, edge_centers=mesh.edge_mesh.centers,
+                       areas=float(g["screening_scale"]) * mesh.areas),
+    )
+
+
+def test_trajectory_with_screening():
+    """include_screening: the heavy-ball iteration of the induced vector potential inside every
+    step (solver.py:522-578, 654-688; 1/r kernel of tdgl/solver/screening.py:12-42)."""
+    g = load_golden("traj_screening_tiny")
+    mesh = reference_mesh(g)
+    sol = _screening_solver(g, mesh).solve()
+    _assert_hip_trajectory(g, sol, 1e-7)
+    assert np.array_equal(sol.dynamics.screening_iterations, g["call_screening_iterations"])
+    assert max_abs(sol.tdgl_data.induced_vector_potential, g["final_A_induced"]) < 1e-9
+    assert np.abs(g["final_A_induced"]).max() > 1e-4  # the fixture really screens
+
+
+def test_screening_iteration_budget_raises_like_reference():
+    g = load_golden("traj_screening_tiny")
+    mesh = reference_mesh(g)
+    solver = _screening_solver(g, mesh, max_iterations_per_step=2)
+    with pytest.raises(RuntimeError, match=r"Screening calculation failed to converge at step 0 after 2 iterations"):
+        solver.solve()
+
+
 def test_trajectory_with_dt_retries():
     g = load_golden("traj_retry_small")
     mesh = reference_mesh(load_golden("mesh_small"))

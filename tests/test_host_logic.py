@@ -72,8 +72,14 @@ def test_solver_options_defaults_and_validation_messages():
     o = SolverOptions(solve_time=1, sparse_solver="superlu")
     o.validate()
     assert o.sparse_solver is SparseSolver.SUPERLU
-    with pytest.raises(SolverOptionsError, match="include_screening"):
-        SolverOptions(solve_time=1, include_screening=True).validate()
+    SolverOptions(solve_time=1, include_screening=True).validate()
+    # messages of tdgl/solver/options.py:107-123
+    with pytest.raises(SolverOptionsError, match="screening_step_drag must be in \\(0, 1\\]"):
+        SolverOptions(solve_time=1, screening_step_drag=0.0).validate()
+    with pytest.raises(SolverOptionsError, match="screening_step_size must be in > 0"):
+        SolverOptions(solve_time=1, screening_step_size=0.0).validate()
+    with pytest.raises(SolverOptionsError, match="screening_tolerance must be in > 0"):
+        SolverOptions(solve_time=1, screening_tolerance=-1.0).validate()
 
 
 # ---------------------------------------------------------------- device, terminals, units
