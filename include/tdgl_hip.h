@@ -200,6 +200,11 @@ int tdgl_set_screening(tdgl_ctx *ctx, const tdgl_screening_options *opts, const 
 /* A_induced [n_edges, 2] in reference edge order (seed / read-out; solver.py:738, 751). */
 int tdgl_set_induced_vector_potential(tdgl_ctx *ctx, const double *A_induced);
 int tdgl_get_induced_vector_potential(tdgl_ctx *ctx, double *A_induced);
+/* One evaluation of the kernel of get_induced_vector_potential (solver.py:549-562;
+ * tdgl/solver/screening.py:12-42, Mesh.get_quantity_on_site tdgl/finite_volume/mesh.py:203-243):
+ * edge_current [n_edges] -> site average -> A_new [n_edges, 2] = sum_j <K>_j area_j / |r_e - r_j|.
+ * No heavy-ball update, A_induced is not touched. */
+int tdgl_induced_vector_potential(tdgl_ctx *ctx, const double *edge_current, double *A_new);
 
 /* ------------------------------------------------------------------ the time loop */
 /* Start a Runner stage (runner.py:294-297, 315-318): time = 0, stage step = 0.  Runner.dt
@@ -264,7 +269,8 @@ int tdgl_vcycle(tdgl_ctx *ctx, const double *r, double *z);
 /* Average duration (ms) of `reps` back-to-back launches of one kernel on the context's
  * stream, timed with HIP events.  kernel: 0 = psi-Laplacian SpMV (K1), 1 = fused
  * psi-Laplacian + rhs, 2 = pointwise psi update, 3 = edge currents, 4 = level-0 Poisson
- * SpMV, 5 = level-0 V-cycle, 6 = copy (device memcpy ceiling, bytes = 16 * n_sites r+w). */
+ * SpMV, 5 = level-0 V-cycle, 6 = copy (device memcpy ceiling, bytes = 16 * n_sites r+w),
+ * 7 = induced vector potential (screening; n_edges * n_sites pairs, ~12 fp64 flops each). */
 int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms);
 /* Enable/disable HIP-event timing of the fused psi-Laplacian kernel inside tdgl_run, and
  * read back the accumulated launches / milliseconds. */

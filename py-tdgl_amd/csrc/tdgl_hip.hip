@@ -711,6 +711,10 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
                 hipLaunchKernelGGL(k_copy_d2, dim3(grid_for(ctx->n_pad)), dim3(BLOCK), 0, ctx->stream,
                                    ctx->n_pad, psi, tmp_c.p);
                 break;
+            case 7:
+                if (!ctx->scr_enabled) return TDGL_ERR_ARG;
+                launch_induced(ctx);
+                break;
             default: return TDGL_ERR_ARG;
         }
         return TDGL_OK;

@@ -203,7 +203,9 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> scr_edge_xy;    // per edge (internal order): x, y  [2 * m_pad]
     tdgl::DevBuf<double> scr_inv_2deg;   // 1 / (2 * number of incident edges)  [n_pad]
     tdgl::DevBuf<double> scr_Jsite;      // site-averaged K = J_s + J_n  [2 * n_pad]
-    tdgl::DevBuf<double> scr_Aind, scr_vel, scr_Anew;  // [2 * m_pad], internal edge order
+    tdgl::DevBuf<double> scr_Aind, scr_vel;  // [2 * m_pad], internal edge order
+    tdgl::DevBuf<double> scr_Anew;           // [scr_chunks][2 * m_pad] partial sums over site chunks
+    int scr_chunks = 1, scr_tiles_per_chunk = 1;
     tdgl::DevBuf<double> abs_sq_old;     // |psi^n|^2 of the step's starting psi [n_pad]
     tdgl::DevBuf<unsigned long long> scr_err_bits;
     int32_t last_screening_iters = 0;

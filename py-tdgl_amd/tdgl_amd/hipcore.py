@@ -316,6 +316,15 @@ class TDGLContext:
             raise ValueError("A_induced must have shape (n_edges, 2)")
         self._chk(self._lib.tdgl_set_induced_vector_potential(self._ctx, p_f64(A)))
 
+    def evaluate_induced_vector_potential(self, edge_current):
+        """One evaluation of the 1/r kernel for an edge current (no heavy-ball update)."""
+        k = f64(edge_current)
+        if k.shape != (self.m,):
+            raise ValueError("edge_current must have shape (n_edges,)")
+        A = np.empty((self.m, 2))
+        self._chk(self._lib.tdgl_induced_vector_potential(self._ctx, p_f64(k), p_f64(A)))
+        return A
+
     def induced_vector_potential(self):
         A = np.empty((self.m, 2))
         self._chk(self._lib.tdgl_get_induced_vector_potential(self._ctx, p_f64(A)))
