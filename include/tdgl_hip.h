@@ -158,6 +158,13 @@ typedef int (*tdgl_halo_fn)(void *user, const double *send, const int64_t *send_
                             const int64_t *recv_off, int32_t n_neighbors, const int32_t *neighbor_ranks);
 typedef int (*tdgl_allreduce_fn)(void *user, double *buf, int64_t count, int32_t op);
 int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn allreduce, void *user);
+/* Overlap of the halo exchanges with the ghost-free rows (default on): the stencil kernels that
+ * follow an exchange (psi Laplacian + rhs; level-0 residual of the V-cycle; A p of the CG) run
+ * their leading ghost-free 256-row tiles on the compute stream while the exchange travels on a
+ * second HIP stream, and the remaining rows after it.  Needs the owned sites numbered interior
+ * first (tdgl_amd.partition does); interior_rows reports the prefix the library found. */
+int tdgl_set_comm_overlap(tdgl_ctx *ctx, int32_t on);
+int tdgl_get_comm_overlap(tdgl_ctx *ctx, int32_t *enabled, int64_t *interior_rows);
 
 /* ------------------------------------------------------------------ inputs */
 /* MeshOperators.set_link_exponents (operators.py:310-383): A[n_edges, 2], dimensionless.

@@ -120,6 +120,9 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (ctx->h_probe_out) (void)hipHostFree(ctx->h_probe_out);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_pack) (void)hipEventDestroy(ctx->ev_pack);
+    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     for (auto &pr : ctx->prof_pending) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -301,6 +304,9 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, ctx->scal.alloc(S_COUNT));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pack, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
     return TDGL_OK;
 }
 
@@ -374,17 +380,34 @@ static int download_edges(tdgl_ctx *ctx, const double *src, double *ref) {
     } while (0)
 
 // ---------------------------------------------------------------------------------------
-static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, double2 *lap) {
-    int per_xcd, grid;
-    sell_grid(ctx->lap_pat.n_slices, &per_xcd, &grid);
+// Tile ranges of the SELL kernels whose rows are the owned sites.  part 0: all tiles; 1: the
+// leading ghost-free tiles (safe to run while a halo exchange is in flight); 2: the rest.
+static inline void tile_range(const tdgl_ctx *ctx, int n_slices, int part, int *tile_base, int *slice_end,
+                              int *tiles) {
+    const int all = (n_slices + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+    const int ni = std::min(ctx->int_tiles, all);
+    if (part == 1) {
+        *tile_base = 0, *tiles = ni, *slice_end = ni * (BLOCK / WAVE);
+    } else if (part == 2) {
+        *tile_base = ni, *tiles = all - ni, *slice_end = n_slices;
+    } else {
+        *tile_base = 0, *tiles = all, *slice_end = n_slices;
+    }
+}
+
+static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, double2 *lap, int part = 0) {
+    int tile_base, slice_end, tiles;
+    tile_range(ctx, ctx->lap_pat.n_slices, part, &tile_base, &slice_end, &tiles);
+    if (tiles <= 0) return;
+    const int per_xcd = (tiles + XCDS - 1) / XCDS, grid = per_xcd * XCDS;
     if (rhs)
-        hipLaunchKernelGGL(k_psi_laplacian<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
-                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
+        hipLaunchKernelGGL(k_psi_laplacian<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd,
+                           tile_base, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
                            ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
                            ctx->ceff.p, ctx->bvec.p);
     else
-        hipLaunchKernelGGL(k_psi_laplacian<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
-                           ctx->lap_pat.n_slices, per_xcd, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
+        hipLaunchKernelGGL(k_psi_laplacian<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd,
+                           tile_base, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
                            ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
                            ctx->cvec.p, ctx->bvec.p);
 }

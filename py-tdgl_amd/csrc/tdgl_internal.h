@@ -131,6 +131,13 @@ struct tdgl_ctx {
     double *h_sendbuf = nullptr, *h_recvbuf = nullptr;  // pinned (callback transport)
     int64_t h_buf_doubles = 0;
     bool fix_psi = true;
+    // halo exchange overlapped with the ghost-free rows (comm.inc): second stream + events
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    int int_tiles = 0;        // leading 256-row tiles whose rows have no ghost neighbour
+    bool overlap = true;      // tdgl_set_comm_overlap
+    double *pend_v = nullptr; // exchange started by comm_halo_start, completed by comm_halo_wait
+    int pend_width = 0;
 
     // permutations (host)
     std::vector<int32_t> perm, iperm;            // internal -> reference site, and inverse

@@ -47,7 +47,8 @@ def stdout_to_stderr():
 
 class DistributedTDGL:
     def __init__(self, mesh, options, link_exponents, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
-                 terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None):
+                 terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
+                 overlap=True):
         import torch.distributed as dist
 
         self.dist = dist
@@ -71,6 +72,7 @@ class DistributedTDGL:
             device_id=dev, n_owned=lp.n_own,
         )
         ctx.set_halo_plan(lp)
+        ctx.set_comm_overlap(overlap)  # halo exchanges hidden behind the ghost-free rows
         if self.world > 1 or transport == "rccl":
             if transport == "rccl":
                 ident = [ctx.comm_unique_id() if self.rank == 0 else None]

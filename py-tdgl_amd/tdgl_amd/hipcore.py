@@ -176,6 +176,15 @@ class TDGLContext:
         self._cb_keep = (_lib.HALO_FN(_halo), _lib.ALLREDUCE_FN(_allreduce))
         self._chk(self._lib.tdgl_comm_init_callbacks(self._ctx, self._cb_keep[0], self._cb_keep[1], None))
 
+    def set_comm_overlap(self, on=True):
+        """Overlap halo exchanges with the ghost-free rows on a second HIP stream (default on)."""
+        self._chk(self._lib.tdgl_set_comm_overlap(self._ctx, int(bool(on))))
+
+    def comm_overlap(self):
+        on, rows = C.c_int32(0), C.c_int64(0)
+        self._chk(self._lib.tdgl_get_comm_overlap(self._ctx, C.byref(on), C.byref(rows)))
+        return bool(on.value), rows.value
+
     def set_hierarchy_distributed(self, h: Hierarchy, lp):
         """Upload the GLOBAL hierarchy ``h`` with level 0 sliced for this rank
         (`partition.local_hierarchy_level0`) and the coarser levels replicated."""

@@ -63,6 +63,7 @@ class LocalProblem:
     send_idx: Dict[int, np.ndarray] = field(default_factory=dict)   # local owned ids per neighbour
     recv_range: Dict[int, tuple] = field(default_factory=dict)      # (start, stop) into local ids
     boundary_positions: np.ndarray = None  # positions (in the GLOBAL boundary list) of local boundary edges
+    n_interior: int = 0                    # leading owned sites with no neighbour on another rank
 
     @property
     def n_loc(self):
@@ -95,6 +96,14 @@ def build_local_problem(mesh, part: np.ndarray, rank: int, fixed_sites=None) -> 
         shape=(len(owned), len(owned)),
     )
     owned = owned[np.asarray(reverse_cuthill_mckee(sub, symmetric_mode=True))]
+    # interior sites (no neighbour on another rank) first, each group in RCM order: the stencil
+    # kernels process that prefix while a halo exchange is in flight (csrc/comm.inc)
+    on_cut = np.zeros(n, dtype=bool)
+    cut_edges = touch & ~both
+    on_cut[e0[cut_edges]] = True
+    on_cut[e1[cut_edges]] = True
+    owned = np.concatenate([owned[~on_cut[owned]], owned[on_cut[owned]]])
+    n_interior = int((~on_cut[owned]).sum())
     # ghosts: the other endpoint of cut edges, grouped by owner, ascending global id inside a group
     ends = np.concatenate([e0[edge_ids], e1[edge_ids]])
     ghosts = np.unique(ends[~own_mask[ends]])
@@ -133,7 +142,7 @@ def build_local_problem(mesh, part: np.ndarray, rank: int, fixed_sites=None) -> 
     fixed_local = g2l[fixed]
     fixed_local = fixed_local[fixed_local >= 0]
     return LocalProblem(
-        rank=rank, world=world, n_global=n, n_own=n_own, local_to_global=l2g,
+        rank=rank, world=world, n_global=n, n_own=n_own, n_interior=n_interior, local_to_global=l2g,
         edge_local_to_global=edge_ids, owned_edge_mask=owned_edge, mesh=lmesh, fixed_sites=fixed_local,
         neighbors=neighbors, send_idx=send_idx, recv_range=recv_range,
         boundary_positions=pos_of_edge[edge_ids[local_b]],

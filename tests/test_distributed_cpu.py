@@ -50,6 +50,15 @@ def test_partition_is_balanced_and_halo_plan_is_consistent(world):
         e = lp.mesh.edge_mesh
         assert np.array_equal(lp.local_to_global[e.edges], mesh.edge_mesh.edges[lp.edge_local_to_global])
     assert np.all(seen == 1)
+    # owned sites are numbered interior first: a local site has a ghost neighbour iff it sits in
+    # [n_interior, n_own) -- the prefix the stencil kernels run while a halo exchange is in flight
+    for lp in lps:
+        e = lp.mesh.edge_mesh.edges
+        ghost_edge = e.max(axis=1) >= lp.n_own
+        has_ghost = np.zeros(lp.n_own, dtype=bool)
+        has_ghost[e.min(axis=1)[ghost_edge]] = True
+        assert 0 < lp.n_interior < lp.n_own
+        assert not has_ghost[: lp.n_interior].any() and has_ghost[lp.n_interior:].all()
     # cut size of a compact partition: far below the edge count
     cut = (part[mesh.edge_mesh.edges[:, 0]] != part[mesh.edge_mesh.edges[:, 1]]).sum()
     assert cut < 0.12 * len(mesh.edge_mesh.edges)

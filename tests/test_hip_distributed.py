@@ -29,15 +29,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _problem():
+def _problem(width=60, height=15):
     for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     from helpers import edge_terminal, synthetic_mesh, uniform_field_A
     from tdgl_amd import SolverOptions
 
-    mesh = synthetic_mesh(60, 15)
-    terms = [edge_terminal(mesh, "source", -30.0), edge_terminal(mesh, "drain", 30.0)]
+    mesh = synthetic_mesh(width, height)
+    terms = [edge_terminal(mesh, "source", -width / 2), edge_terminal(mesh, "drain", width / 2)]
     A = uniform_field_A(mesh, 0.05)
     em = mesh.edge_mesh
     mu_b = np.zeros(len(em.boundary_edge_indices))
@@ -51,9 +51,9 @@ def _problem():
     return mesh, terms, A, mu_b, opts, probes, psi0
 
 
-def _worker(rank, world, port, transport, out_dir):
+def _worker(rank, world, port, transport, out_dir, overlap=True, size=(60, 15)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    mesh, terms, A, mu_b, opts, probes, psi0 = _problem()
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(*size)
     from tdgl_amd import _lib  # noqa: F401  (load libtdgl_hip and its ROCm runtime before torch)
 
     _lib.load()
@@ -64,21 +64,23 @@ def _worker(rank, world, port, transport, out_dir):
         from tdgl_amd.distributed import DistributedTDGL
 
         run = DistributedTDGL(mesh, opts, A, 1.0, rank=rank, world=world, terminal_info=terms, mu_boundary=mu_b,
-                              probe_points=probes, transport=transport, device_id=0)
+                              probe_points=probes, transport=transport, device_id=0, overlap=overlap)
         run.set_state(psi0, np.zeros(len(mesh.sites)))
         run.begin_stage()
         res = run.run(N_STEPS)
         fields = run.gather_state()
         if rank == 0:
+            on, rows = run.ctx.comm_overlap()
             np.savez(os.path.join(out_dir, f"dist_{transport}_{world}.npz"), dt=res["dt"], mu_probe=res["mu"],
-                     theta_probe=res["theta"], iters=res["pcg_iters"], **fields)
+                     theta_probe=res["theta"], iters=res["pcg_iters"], overlap=on, interior_rows=rows,
+                     n_own=run.lp.n_own, n_interior=run.lp.n_interior, **fields)
         run.close()
     finally:
         dist.destroy_process_group()
 
 
-def _single_gpu_reference():
-    mesh, terms, A, mu_b, opts, probes, psi0 = _problem()
+def _single_gpu_reference(size=(60, 15)):
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(*size)
     from tdgl_amd import TDGLSolver
 
     cur = {"source": 6.0, "drain": -6.0}
@@ -108,6 +110,25 @@ def test_multi_rank_run_matches_single_gpu(world, tmp_path):
     assert np.abs((got["mu_probe"][:, 0] - got["mu_probe"][:, 1]) - (ref_res["mu"][:, 0] - ref_res["mu"][:, 1])).max() < 1e-9
     # the decomposition must not change the iteration count materially
     assert abs(got["iters"].mean() - ref_res["pcg_iters"].mean()) < 2.0
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_halo_overlap_on_second_stream_matches_single_gpu(overlap, tmp_path):
+    """16k-site film on 3 ranks: most 256-row tiles are ghost-free, so the stencil kernels run
+    split (interior while the exchange is in flight on the communication stream, boundary rows
+    after it); with the overlap disabled the same run uses the plain exchange-then-kernel order."""
+    size = (120, 120)
+    mesh, ref_res, ref = _single_gpu_reference(size)
+    mp.spawn(_worker, args=(3, _free_port(), "gloo", str(tmp_path), overlap, size), nprocs=3, join=True)
+    got = np.load(os.path.join(tmp_path, "dist_gloo_3.npz"))
+    assert bool(got["overlap"]) == overlap
+    assert int(got["interior_rows"]) >= 0.8 * int(got["n_interior"]) - 256 > 1000
+    assert int(got["n_interior"]) < int(got["n_own"])
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-9
+    assert np.abs(got["mu"] - ref["mu"]).max() < 1e-9 * max(1.0, np.abs(ref["mu"]).max())
+    assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-9
+    assert np.abs(got["normal_current"] - ref["normal_current"]).max() < 1e-9
 
 
 def test_rccl_transport_world_size_one(tmp_path):
