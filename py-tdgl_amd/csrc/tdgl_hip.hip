@@ -176,11 +176,17 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     }
     ctx->edge_perm.resize(m);
     std::iota(ctx->edge_perm.begin(), ctx->edge_perm.end(), 0);
+    // (one-process-per-GPU mode: edges that touch a ghost site go last, so that the edges between
+    // owned sites form a prefix the edge kernel can process while ghost values travel)
     std::sort(ctx->edge_perm.begin(), ctx->edge_perm.end(), [&](int32_t a, int32_t b) {
         const int32_t alo = std::min(p0[a], p1[a]), ahi = std::max(p0[a], p1[a]);
         const int32_t blo = std::min(p0[b], p1[b]), bhi = std::max(p0[b], p1[b]);
+        const bool ag = ahi >= ctx->n_own, bg = bhi >= ctx->n_own;
+        if (ag != bg) return bg;
         return alo != blo ? alo < blo : (ahi != bhi ? ahi < bhi : a < b);
     });
+    ctx->m_int = 0;
+    for (int64_t e = 0; e < m; ++e) ctx->m_int += std::max(p0[e], p1[e]) < ctx->n_own ? 1 : 0;
     ctx->edge_iperm.resize(m);
     for (int64_t k = 0; k < m; ++k) ctx->edge_iperm[ctx->edge_perm[k]] = (int32_t)k;
 
@@ -419,21 +425,22 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
                        ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p, abs_sq_in);
 }
 
+// part 0: all edges; 1: edges between owned sites; 2: edges touching a ghost site
 static void launch_edge_currents(tdgl_ctx *ctx, const double2 *psi, const double *mu, double *js,
-                                 double *jn) {
-    const int grid = grid_for(ctx->m);
+                                 double *jn, int part = 0) {
+    const int64_t base = (part == 2) ? ctx->m_int : 0, end = (part == 1) ? ctx->m_int : ctx->m;
+    if (end <= base) return;
+    const int grid = grid_for(end - base);
+    const double *dadt = ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr;
     if (js && jn)
-        hipLaunchKernelGGL((k_edge_currents<true, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn,
-                           ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr);
+        hipLaunchKernelGGL((k_edge_currents<true, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, end,
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn, dadt, base);
     else if (js)
-        hipLaunchKernelGGL((k_edge_currents<true, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn,
-                           ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr);
+        hipLaunchKernelGGL((k_edge_currents<true, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, end,
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn, dadt, base);
     else if (jn)
-        hipLaunchKernelGGL((k_edge_currents<false, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn,
-                           ctx->has_dadt ? ctx->e_dAdt.p : (const double *)nullptr);
+        hipLaunchKernelGGL((k_edge_currents<false, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, end,
+                           ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, psi, mu, js, jn, dadt, base);
 }
 
 static void refresh_ceff(tdgl_ctx *ctx) {

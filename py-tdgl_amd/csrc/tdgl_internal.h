@@ -135,6 +135,8 @@ struct tdgl_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
     int int_tiles = 0;        // leading 256-row tiles whose rows have no ghost neighbour
+    int64_t m_int = 0;        // leading edges (internal order) between two owned sites
+    bool defer_mu_halo = false;  // pcg_solve leaves the exchange of mu's ghosts pending (run.inc)
     bool overlap = true;      // tdgl_set_comm_overlap
     double *pend_v = nullptr; // exchange started by comm_halo_start, completed by comm_halo_wait
     int pend_width = 0;
