@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--nu", type=int, default=2, help="smoother degree on the coarse levels")
     ap.add_argument("--nu-fine", type=int, default=1, help="smoother degree on level 0")
     ap.add_argument("--extrapolate", type=int, default=2, help="initial-guess extrapolation order (0, 1, 2)")
+    ap.add_argument("--no-fused-restriction", action="store_true",
+                    help="restrict the level-0 residual with two kernels instead of the pre-multiplied operator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--kernel-reps", type=int, default=50)
@@ -207,7 +209,8 @@ def main():
         log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
     ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                             edge_currents_every_step=True, smoother=args.smoother,
-                            extrapolate=args.extrapolate, nu_fine=args.nu_fine)
+                            extrapolate=args.extrapolate, nu_fine=args.nu_fine,
+                            fused_restriction=not args.no_fused_restriction)
     h = ctx.hierarchy
     log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")
     ctx.begin_stage()

@@ -127,6 +127,13 @@ int tdgl_synchronize(tdgl_ctx *ctx);
 int tdgl_poisson_set_hierarchy(tdgl_ctx *ctx, const tdgl_amg_level *levels, int32_t n_levels,
                                const double *coarse_pinv);
 int tdgl_set_poisson_options(tdgl_ctx *ctx, const tdgl_poisson_options *opts);
+/* Optional accelerator of the V-cycle: M = R_0 (I - c A_0 D_0^-1) as CSR [n_1, n_0], c = the
+ * level-0 smoothing coefficient in use (degree-1 smoothing).  Restricting the pre-smoothed
+ * residual then is one product with M instead of a pass over A_0 plus the restriction.  Pure
+ * algebraic re-association: the V-cycle is the same operator.  indptr == NULL switches it off;
+ * replaced hierarchies drop it.  Ignored in one-process-per-GPU mode. */
+int tdgl_poisson_set_fused_restriction(tdgl_ctx *ctx, int64_t n_rows, int64_t n_cols, const int32_t *indptr,
+                                       const int32_t *indices, const double *data, double c);
 
 /* ------------------------------------------------------------------ one process per GPU
  * The reference is single-process.  Here the mesh is cut into `world` pieces (host layer:

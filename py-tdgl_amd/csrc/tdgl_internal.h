@@ -178,6 +178,8 @@ struct tdgl_ctx {
 
     // ---- Poisson ---------------------------------------------------------------------
     std::vector<tdgl::AmgLevel *> levels;
+    tdgl::Csr fusedR;                     // R0 (I - c A0 D0^-1): restriction of the pre-smoothed residual
+    double fusedR_c = 0.0;                // the smoothing coefficient it was built for
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;

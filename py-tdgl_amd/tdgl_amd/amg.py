@@ -229,6 +229,17 @@ def smoother_coefficients(rho, nu=2, smoother="chebyshev", cheb_lo=0.1):
     return c1, c2
 
 
+def fused_restriction(h: Hierarchy, c: float) -> sp.csr_matrix:
+    """``R_0 (I - c A_0 D_0^-1)``: restriction of the residual left by ONE smoothing step
+    ``x = c D^-1 b`` from a zero guess, as a single operator on ``b``."""
+    lv = h.levels[0]
+    A, R = lv.A.tocsr(), lv.R.tocsr()
+    M = R - (R @ A) @ sp.diags(c * lv.dinv)
+    M = M.tocsr()
+    M.sort_indices()
+    return M
+
+
 def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 2, smoother: str = "chebyshev",
                 cheb_lo: float = 0.1, lvl: int = 0, nu_fine: int = 0) -> np.ndarray:
     """``nu_fine`` > 0 overrides the smoother degree on level 0 (the library's default is

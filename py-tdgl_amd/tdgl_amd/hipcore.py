@@ -224,17 +224,38 @@ class TDGLContext:
         pinv = f64(h.coarse_pinv)
         self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
         self.hierarchy = h
+        self._refresh_fused_restriction()
+
+    def _refresh_fused_restriction(self):
+        """(Re)build R0 (I - c A0 D0^-1) for the level-0 smoothing coefficient in use
+        (single-GPU, degree-1 smoothing on level 0; `tdgl_poisson_set_fused_restriction`)."""
+        h, o = getattr(self, "hierarchy", None), getattr(self, "poisson_options", None)
+        if h is None or o is None or self.n_owned != self.n or len(h.levels) < 2:
+            return
+        if o["nu_fine"] != 1 or not o.get("fused_restriction", True):
+            self._chk(self._lib.tdgl_poisson_set_fused_restriction(self._ctx, 0, 0, None, None, None, 0.0))
+            return
+        from .amg import fused_restriction, smoother_coefficients
+
+        name = "jacobi" if o["smoother"] == 0 else "chebyshev"
+        c = smoother_coefficients(h.levels[0].rho, 1, name, o["cheb_lo"])[1][0]
+        M = fused_restriction(h, c)
+        ip, ix, dx = i32(M.indptr), i32(M.indices), f64(M.data)
+        self._chk(self._lib.tdgl_poisson_set_fused_restriction(
+            self._ctx, M.shape[0], M.shape[1], p_i32(ip), p_i32(ix), p_f64(dx), float(c)))
 
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
-                            extrapolate=2, nu_fine=1):
+                            extrapolate=2, nu_fine=1, fused_restriction=True):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
                                 int(extrapolate), int(nu_fine))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
-                                    smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate))
+                                    smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
+                                    fused_restriction=bool(fused_restriction))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
+        self._refresh_fused_restriction()
 
     # -- inputs ---------------------------------------------------------------------------
     def set_link_exponents(self, A):

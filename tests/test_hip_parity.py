@@ -143,6 +143,24 @@ def test_vcycle_matches_host_restatement(small_ctx):
     ctx.set_poisson_options(rtol=1e-12)
 
 
+def test_fused_restriction_is_the_same_vcycle(small_ctx):
+    """R0 (I - c A0 D0^-1) as one operator (tdgl_poisson_set_fused_restriction) vs the level-0
+    residual kernel followed by the restriction: same V-cycle, re-associated."""
+    ctx, mesh, g = small_ctx
+    rng = np.random.default_rng(11)
+    r = rng.standard_normal(len(mesh.sites))
+    r -= r.mean()
+    o = dict(ctx.poisson_options)
+    kw = dict(rtol=o["rtol"], max_iter=o["max_iter"], nu=o["nu"], check_every=o["check_every"],
+              smoother=o["smoother"], cheb_lo=o["cheb_lo"], extrapolate=o["extrapolate"], nu_fine=1)
+    ctx.set_poisson_options(**kw, fused_restriction=False)
+    z_plain = ctx.vcycle(r)
+    ctx.set_poisson_options(**kw, fused_restriction=True)
+    z_fused = ctx.vcycle(r)
+    assert max_abs(z_fused, z_plain) < 1e-13 * np.abs(z_plain).max()
+    assert np.abs(z_plain).max() > 0
+
+
 def test_psi_update_matches_reference_including_failures():
     from tdgl_amd.hipcore import TDGLContext
 
