@@ -134,6 +134,14 @@ int tdgl_set_poisson_options(tdgl_ctx *ctx, const tdgl_poisson_options *opts);
  * replaced hierarchies drop it.  Ignored in one-process-per-GPU mode. */
 int tdgl_poisson_set_fused_restriction(tdgl_ctx *ctx, int64_t n_rows, int64_t n_cols, const int32_t *indptr,
                                        const int32_t *indices, const double *data, double c);
+/* Optional, for a level 1 <= level < n_levels - 1: R A [n_coarse x n] and A P [n x n_coarse] as CSR,
+ * plus P's values laid out on A P's sparsity pattern (0 where P has no entry).  The restricted
+ * residual R b - (R A) x and "prolongate, then first post-smoothing step" then take one launch
+ * each; the coarse levels are launch-latency bound, not bandwidth bound.  ra_indptr == NULL
+ * switches it off for that level. */
+int tdgl_poisson_set_fused_level(tdgl_ctx *ctx, int32_t level, const int32_t *ra_indptr, const int32_t *ra_indices,
+                                 const double *ra_data, const int32_t *ap_indptr, const int32_t *ap_indices,
+                                 const double *ap_data, const double *p_on_ap_data);
 
 /* ------------------------------------------------------------------ one process per GPU
  * The reference is single-process.  Here the mesh is cut into `world` pieces (host layer:

@@ -94,6 +94,11 @@ struct AmgLevel {
     SellF64 P;                       // prolongation n x n_coarse (level 0)
     Csr Pc, R;                       // prolongation (levels >= 1); restriction n_coarse x n
     DevBuf<double> xa, xb, d, b, r;  // level vectors (level 0 borrows b from PCG)
+    // optional pre-multiplied operators of a coarse level (tdgl_poisson_set_fused_level)
+    bool fused = false;
+    Csr RA;                          // R A   [n_coarse x n]
+    Csr AP;                          // A P   [n x n_coarse]
+    DevBuf<double> APp;              // P on the pattern of A P
 };
 
 // scalars of the PCG recurrence, resident on the device
@@ -183,6 +188,7 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
+    tdgl::DevBuf<double> pcg_p2;          // second direction buffer (fused direction update, k_sell_axp)
     tdgl::DevBuf<double> part_pair[2];    // 2 x NB partials each: [r.z | ||r||^2], ping-pong
     tdgl::DevBuf<double> part_pq, part_tmp;  // NB per-workgroup partials each
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)

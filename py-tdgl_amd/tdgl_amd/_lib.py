@@ -127,6 +127,9 @@ SIGNATURES = {
     "tdgl_synchronize": (C.c_int, [_CTX]),
     "tdgl_poisson_set_hierarchy": (C.c_int, [_CTX, C.POINTER(AmgLevel), C.c_int32, c_f64p]),
     "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
+    "tdgl_poisson_set_fused_level": (
+        C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p]
+    ),
     "tdgl_poisson_set_fused_restriction": (
         C.c_int, [_CTX, C.c_int64, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double]
     ),

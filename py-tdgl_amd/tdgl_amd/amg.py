@@ -240,6 +240,34 @@ def fused_restriction(h: Hierarchy, c: float) -> sp.csr_matrix:
     return M
 
 
+def fused_level_operators(level):
+    """``(R A, A P, P on the pattern of A P)`` of a coarse level as CSR matrices / value array
+    (`tdgl_poisson_set_fused_level`)."""
+    A, P, R = level.A.tocsr(), level.P.tocsr(), level.R.tocsr()
+    RA = (R @ A).tocsr()
+    RA.sort_indices()
+    AP = (A @ P).tocsr()
+    # union pattern (P's pattern is contained in A P's whenever diag(A) != 0; do not rely on it),
+    # then both value sets laid out on it (SciPy's sparse sum drops explicit zeros, so by hand)
+    def keys(M):
+        M = M.tocsr()
+        M.sort_indices()
+        rows = np.repeat(np.arange(M.shape[0], dtype=np.int64), np.diff(M.indptr))
+        return rows * M.shape[1] + M.indices, M.data
+
+    k_ap, v_ap = keys(AP)
+    k_p, v_p = keys(P)
+    k_u = np.union1d(k_ap, k_p)
+    ap_vals = np.zeros(len(k_u))
+    p_vals = np.zeros(len(k_u))
+    ap_vals[np.searchsorted(k_u, k_ap)] = v_ap
+    p_vals[np.searchsorted(k_u, k_p)] = v_p
+    rows_u, cols_u = k_u // AP.shape[1], k_u % AP.shape[1]
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(rows_u, minlength=AP.shape[0]))])
+    AP_u = sp.csr_matrix((ap_vals, cols_u, indptr), shape=AP.shape)
+    return RA, AP_u, p_vals
+
+
 def vcycle_host(h: Hierarchy, b: np.ndarray, nu: int = 2, smoother: str = "chebyshev",
                 cheb_lo: float = 0.1, lvl: int = 0, nu_fine: int = 0) -> np.ndarray:
     """``nu_fine`` > 0 overrides the smoother degree on level 0 (the library's default is

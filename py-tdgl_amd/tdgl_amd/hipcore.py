@@ -225,6 +225,22 @@ class TDGLContext:
         self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
         self.hierarchy = h
         self._refresh_fused_restriction()
+        self._set_fused_levels(h)
+
+    def _set_fused_levels(self, h, on=True):
+        """Pre-multiplied transfer operators of the coarse levels (one launch instead of two on
+        the way down and on the way up; `tdgl_poisson_set_fused_level`)."""
+        from .amg import fused_level_operators
+
+        for k in range(1, len(h.levels) - 1):
+            if not on:
+                self._chk(self._lib.tdgl_poisson_set_fused_level(self._ctx, k, None, None, None, None, None, None, None))
+                continue
+            RA, AP, p_on_ap = fused_level_operators(h.levels[k])
+            a = [i32(RA.indptr), i32(RA.indices), f64(RA.data), i32(AP.indptr), i32(AP.indices), f64(AP.data),
+                 f64(p_on_ap)]
+            self._chk(self._lib.tdgl_poisson_set_fused_level(
+                self._ctx, k, p_i32(a[0]), p_i32(a[1]), p_f64(a[2]), p_i32(a[3]), p_i32(a[4]), p_f64(a[5]), p_f64(a[6])))
 
     def _refresh_fused_restriction(self):
         """(Re)build R0 (I - c A0 D0^-1) for the level-0 smoothing coefficient in use
