@@ -94,6 +94,8 @@ struct AmgLevel {
     SellF64 P;                       // prolongation n x n_coarse (level 0)
     Csr Pc, R;                       // prolongation (levels >= 1); restriction n_coarse x n
     DevBuf<double> xa, xb, d, b, r;  // level vectors (level 0 borrows b from PCG)
+    // fp32 copies of the level-0 V-cycle operators / iterates (mixed-precision preconditioner)
+    DevBuf<float> A32, P32, dinv32, x32a, x32b;
     // optional pre-multiplied operators of a coarse level (tdgl_poisson_set_fused_level)
     bool fused = false;
     Csr RA;                          // R A   [n_coarse x n]
@@ -185,6 +187,8 @@ struct tdgl_ctx {
     std::vector<tdgl::AmgLevel *> levels;
     tdgl::Csr fusedR;                     // R0 (I - c A0 D0^-1): restriction of the pre-smoothed residual
     double fusedR_c = 0.0;                // the smoothing coefficient it was built for
+    tdgl::DevBuf<float> fusedR32;         // its values in fp32
+    bool f32_ready = false;               // fp32 copies are current
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
@@ -194,7 +198,7 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
     tdgl::DevBuf<double> mu_prev, mu_prev2;  // mu^{n-1}, mu^{n-2} for the extrapolated initial guess
     double prev_dt = 0.0, prev_dt2 = 0.0;    // dt of the steps that produced mu / mu_prev (0: no history)
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 2, 1};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 2, 1, 1};
     int32_t last_pcg_iters = 0;
     double last_relres = 0.0;
 

@@ -104,6 +104,7 @@ class PoissonOptions(C.Structure):
         ("cheb_lo", C.c_double),
         ("extrapolate", C.c_int32),
         ("nu_fine", C.c_int32),
+        ("precond_fp32", C.c_int32),
     ]
 
 

@@ -262,14 +262,14 @@ class TDGLContext:
 
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
-                            extrapolate=2, nu_fine=1, fused_restriction=True):
+                            extrapolate=2, nu_fine=1, fused_restriction=True, precond_fp32=True):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
-                                int(extrapolate), int(nu_fine))
+                                int(extrapolate), int(nu_fine), int(bool(precond_fp32)))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
-                                    fused_restriction=bool(fused_restriction))
+                                    fused_restriction=bool(fused_restriction), precond_fp32=bool(precond_fp32))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
         self._refresh_fused_restriction()
 
