@@ -41,8 +41,8 @@ B_FIELD = 0.1  # B / Bc2
 
 # HBM bytes per launch of the fused psi-Laplacian kernel from rocprofv3 PMC counters
 # ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction calibrated on a copy kernel in the same
-# run: profiles/r01_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
-PMC_TRAFFIC_BYTES = {"1M": 192.4e6}
+# run: profiles/r01f_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
+PMC_TRAFFIC_BYTES = {"1M": 188.2e6}
 
 
 def log(*a):
@@ -267,7 +267,7 @@ def main():
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 4),
         traffic=PMC_TRAFFIC_BYTES.get(args.workload) if not use_dd else None,
-        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_pmc_hbm_traffic_1M.txt",
+        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01f_pmc_hbm_traffic_1M.txt",
         algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"],
         avg_launch_ms=round(k1_avg_ms, 5),
         launches=launches,
@@ -297,7 +297,9 @@ def main():
         data="synthetic",
         config=dict(
             workload=f"{desc}, " + ("" if strip else f"uniform field b=B/Bc2={B_FIELD}, ") + f"adaptive dt (dt_init 1e-4, dt_max 0.1), "
-                     f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below), J_s/J_n formed every step",
+                     f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
+                     + ("" if args.precond_fp64 else "; level-0 operators of the V-cycle stored in fp32, all arithmetic and the CG in fp64")
+                     + "), J_s/J_n formed every step",
             sites=n, edges=m, amg_levels=h.sizes,
             parallelism="single" if world == 1 else
             f"domain decomposition (RCB, {world} ranks, ~{n // world} sites each), RCCL halo exchange + all-reduce",
