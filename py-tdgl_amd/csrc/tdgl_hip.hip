@@ -310,6 +310,9 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, ctx->scal.alloc(S_COUNT));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
+    ctx->psi_blocks = (int)std::min<int64_t>(std::max<int64_t>(grid_for(ctx->n_own), 1), 2048);
+    HIP_TRY(ctx, ctx->psi_dmax_part.alloc(ctx->psi_blocks));
+    HIP_TRY(ctx, ctx->psi_fail_part.alloc(ctx->psi_blocks));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pack, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
@@ -420,9 +423,19 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
 
 static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
                               double dt, double2 *psi_new, double *abs_sq, const double *abs_sq_in = nullptr) {
-    const int grid = std::min<int64_t>(grid_for(ctx->n_own), 2048);
-    hipLaunchKernelGGL(k_psi_update, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->n_own, psi, mu,
-                       ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->d_status.p, abs_sq_in);
+    hipLaunchKernelGGL(k_psi_update, dim3(ctx->psi_blocks), dim3(BLOCK), 0, ctx->stream, ctx->n_own, psi, mu,
+                       ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new, abs_sq, ctx->psi_dmax_part.p,
+                       ctx->psi_fail_part.p, abs_sq_in);
+    ctx->psi_status_pending = true;
+}
+
+// reduce the outcome of the last psi update into d_status (together with the PCG scalars)
+static void publish_status(tdgl_ctx *ctx) {
+    const bool psi = ctx->psi_status_pending;
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d_status.p, ctx->scal.p,
+                       psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
+                       psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks);
+    ctx->psi_status_pending = false;
 }
 
 // part 0: all edges; 1: edges between owned sites; 2: edges touching a ghost site
@@ -654,9 +667,9 @@ extern "C" int tdgl_psi_update(tdgl_ctx *ctx, const double *psi, const double *m
     HIP_TRY(ctx, s.r1.alloc(ctx->n_pad));
     TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), s.c0));
     TDGL_TRY(upload_sites(ctx, mu, s.r0));
-    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status.p);
     launch_psi_laplacian(ctx, false, s.c0.p, lap.p);
     launch_psi_update(ctx, s.c0.p, s.r0.p, lap.p, dt, pnew.p, s.r1.p);
+    publish_status(ctx);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status.p, sizeof(StepStatus), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -760,8 +773,7 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms = (double)ms / reps;
-    // the step status may have been touched by the psi-update kernel; reset it
-    hipLaunchKernelGGL(k_reset_status, dim3(1), dim3(64), 0, ctx->stream, ctx->d_status.p);
+    ctx->psi_status_pending = false;  // (the psi-update kernel may have run on scratch data)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TDGL_OK;
 }

@@ -203,6 +203,10 @@ struct tdgl_ctx {
     double last_relres = 0.0;
 
     // ---- step status / probes --------------------------------------------------------
+    tdgl::DevBuf<double> psi_dmax_part;    // per-workgroup max d|psi|^2 of the last k_psi_update
+    tdgl::DevBuf<int32_t> psi_fail_part;   // per-workgroup failure flags
+    int psi_blocks = 0;                    // its grid
+    bool psi_status_pending = false;       // not yet reduced into d_status
     tdgl::DevBuf<tdgl::StepStatus> d_status;
     tdgl::StepStatus *h_status = nullptr;  // pinned
     std::vector<int32_t> probes;           // internal site ids
