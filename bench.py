@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--nu", type=int, default=2, help="smoother degree on the coarse levels")
     ap.add_argument("--nu-fine", type=int, default=1, help="smoother degree on level 0")
     ap.add_argument("--extrapolate", type=int, default=2, help="initial-guess extrapolation order (0, 1, 2)")
+    ap.add_argument("--cheb-lo", type=float, default=0.1, help="Chebyshev smoothing interval [cheb_lo * rho, rho]")
     ap.add_argument("--precond-fp64", action="store_true",
                     help="keep the level-0 operators of the V-cycle in fp64 (default: fp32 storage inside the fp64 CG)")
     ap.add_argument("--no-fused-restriction", action="store_true",
@@ -212,7 +213,7 @@ def main():
     ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                             edge_currents_every_step=True, smoother=args.smoother,
                             extrapolate=args.extrapolate, nu_fine=args.nu_fine,
-                            fused_restriction=not args.no_fused_restriction,
+                            fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
                             precond_fp32=not args.precond_fp64)
     h = ctx.hierarchy
     log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")

@@ -367,9 +367,9 @@ class Device:
         Rectangular, hole-free films get a jittered triangular lattice; any other polygon
         (holes included) a boundary-conforming Delaunay mesh of such a lattice
         (`meshgen.polygon_mesh`).  Edges do not exceed ``max_edge_length`` (default: one
-        coherence length, as in the reference).  ``smooth`` is accepted and ignored (the
-        lattice is already near-equilateral).  A mesh made elsewhere can be installed with
-        :meth:`mesh_from_triangulation`.
+        coherence length, as in the reference).  ``smooth`` > 0 applies that many iterations of
+        the reference's Laplacian smoothing (`Mesh.smooth`) before the dual mesh is built.  A
+        mesh made elsewhere can be installed with :meth:`mesh_from_triangulation`.
         """
         if max_edge_length is None or max_edge_length <= 0:
             max_edge_length = 1.0 * self.layer.coherence_length
@@ -380,7 +380,7 @@ class Device:
                 if min_points is None or len(pts) >= min_points:
                     break
                 max_edge_length *= 0.9
-            self.mesh_from_triangulation(pts, tri)
+            self.mesh_from_triangulation(pts, tri, smooth=smooth)
             return
         (x0, y0), (x1, y1) = self.film.bbox
         width, height = x1 - x0, y1 - y0
@@ -390,14 +390,19 @@ class Device:
                 break
             max_edge_length *= 0.9
         pts = pts + np.array([[0.5 * (x0 + x1), 0.5 * (y0 + y1)]])
-        self.mesh_from_triangulation(pts, tri)
+        self.mesh_from_triangulation(pts, tri, smooth=smooth)
 
-    def mesh_from_triangulation(self, points, triangles) -> None:
+    def mesh_from_triangulation(self, points, triangles, smooth: int = 0) -> None:
         """Install a mesh given in ``length_units`` (`_create_dimensionless_mesh`,
-        device.py:568-583)."""
+        device.py:568-583), optionally after ``smooth`` Laplacian smoothing iterations
+        (device.py:552-556)."""
         points = np.asarray(points, dtype=float)
+        triangles = np.asarray(triangles)
+        if smooth:
+            points = Mesh.from_triangulation(points, triangles, create_submesh=False).smooth(
+                smooth, create_submesh=False).sites
         self.mesh = Mesh.from_triangulation(
-            points / self.layer.coherence_length, np.asarray(triangles), create_submesh=True
+            points / self.layer.coherence_length, triangles, create_submesh=True
         )
 
     # -- terminals --------------------------------------------------------------------------

@@ -60,6 +60,55 @@ def circumcenters(sites: np.ndarray, elements: np.ndarray) -> np.ndarray:
     return np.column_stack([cx, cy]) + p0
 
 
+def _reference_hull_areas(areas, which, sites, elements, cc, edges, boundary_edge_indices, boundary_indices):
+    """Cell areas the way the reference builds them (`tdgl/finite_volume/util.py:169-277`), for the
+    sites in ``which`` (those with a circumcentre on the far side of an incident edge -- obtuse
+    boundary triangles, smoothed / non-Delaunay connectivity), overwriting ``areas`` there.
+
+    Interior site: area of the convex hull of the incident triangles' circumcentres (the reference
+    refuses a non-convex cell).  Boundary site: hull of circumcentres + the two adjacent
+    boundary-edge midpoints + the site itself; if those points are not in convex position, the
+    triangle (midpoint, midpoint, site) is subtracted.  On such cells this is NOT the Voronoi area
+    (the cells overlap), but it is what the reference's operators are built from.
+    """
+    from scipy.spatial import ConvexHull, QhullError
+
+    def hull_area(pts):
+        try:
+            hull = ConvexHull(pts)
+        except QhullError:  # collinear
+            return 0.0, True
+        return hull.volume, len(hull.vertices) == len(pts)
+
+    is_boundary = np.zeros(len(sites), dtype=bool)
+    is_boundary[boundary_indices] = True
+    bedges = edges[boundary_edge_indices]
+    which_set = np.zeros(len(sites), dtype=bool)
+    which_set[which] = True
+    # incident triangles of the requested sites
+    tri_of = {int(i): [] for i in which}
+    for t, tri in enumerate(elements):
+        for v in tri:
+            if which_set[v]:
+                tri_of[int(v)].append(t)
+    for i in which:
+        poly = cc[tri_of[int(i)]]
+        if not is_boundary[i]:
+            area, convex = hull_area(poly)
+            if not convex:
+                raise ValueError(
+                    f"Malformed Voronoi cell surrounding site {int(i)}: all interior Voronoi cells must be convex."
+                )
+            areas[i] = area
+            continue
+        mids = sites[bedges[(bedges == i).any(axis=1)]].mean(axis=1)
+        pts = np.concatenate([poly, mids, sites[i][None, :]], axis=0)
+        area, convex = hull_area(pts)
+        if not convex:
+            area -= hull_area(np.concatenate([mids, sites[i][None, :]], axis=0))[0]
+        areas[i] = area
+
+
 class EdgeMesh:
     """Edge-centred quantities of a triangular mesh."""
 
@@ -169,6 +218,7 @@ class Mesh:
         # the circumcentre above the edge (positive towards r) times |pq|/4 goes to both
         # p and q.
         areas = np.zeros(n, dtype=float)
+        suspicious = np.zeros(n, dtype=bool)
         for k, (ip, iq, ir) in enumerate([(0, 1, 2), (1, 2, 0), (2, 0, 1)]):
             p = sites[elements[:, ip]]
             q = sites[elements[:, iq]]
@@ -183,6 +233,14 @@ class Mesh:
             contrib = 0.25 * length * h
             np.add.at(areas, elements[:, ip], contrib)
             np.add.at(areas, elements[:, iq], contrib)
+            # a circumcentre on the far side of its edge: the cell of both end sites needs the
+            # reference's hull-based construction (below)
+            neg = h < -1e-14 * length
+            suspicious[elements[neg, ip]] = True
+            suspicious[elements[neg, iq]] = True
+        if suspicious.any():
+            _reference_hull_areas(areas, np.flatnonzero(suspicious), sites, elements, cc, edges,
+                                  boundary_edge_indices, boundary_indices)
 
         edge_mesh = EdgeMesh(
             centers, edges, boundary_edge_indices, directions, edge_lengths, dual
@@ -195,6 +253,25 @@ class Mesh:
             dual_sites=cc,
             edge_mesh=edge_mesh,
         )
+
+    def smooth(self, iterations: int, create_submesh: bool = True) -> "Mesh":
+        """Laplacian smoothing (`tdgl/finite_volume/mesh.py:245-283`): every interior vertex moves
+        to the mean of its neighbours, ``iterations`` times, at fixed connectivity; boundary
+        vertices stay.  Returns a new mesh."""
+        edges, _, _ = unique_edges(self.elements, len(self.sites))
+        n = len(self.sites)
+        degree = np.bincount(edges.ravel(), minlength=n)
+        boundary = self.boundary_indices
+        sites = np.asarray(self.sites, dtype=float)
+        for _ in range(int(iterations)):
+            new = np.zeros((n, 2))
+            for k in range(2):
+                new[:, k] = np.bincount(edges[:, 0], sites[edges[:, 1], k], minlength=n)
+                new[:, k] += np.bincount(edges[:, 1], sites[edges[:, 0], k], minlength=n)
+            new /= degree[:, None]
+            new[boundary] = sites[boundary]
+            sites = new
+        return Mesh.from_triangulation(sites, self.elements, create_submesh=create_submesh)
 
     def get_quantity_on_site(self, quantity_on_edge, vector: bool = True):
         """Edge -> site averaging (`tdgl/finite_volume/mesh.py:203-243`): mean over the

@@ -115,7 +115,10 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
         poly = np.asarray(poly, dtype=float)
         if np.allclose(poly[0], poly[-1]):
             poly = poly[:-1]
-        loops.append(poly)
+        # repeated vertices (polygon generators repeat corner points) would be zero-length
+        # boundary segments
+        keep = np.linalg.norm(poly - np.roll(poly, 1, axis=0), axis=1) > 1e-12 * max(1.0, np.abs(poly).max())
+        loops.append(poly[keep])
 
     def resample(loop):
         pts = []

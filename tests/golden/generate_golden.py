@@ -290,6 +290,9 @@ def main():
     pts = np.concatenate([ring, inner])
     irregular = RefMesh.from_triangulation(pts, triangulate(pts))
     save("mesh_irregular", **mesh_arrays(irregular))
+    # the reference's Laplacian smoothing (finite_volume/mesh.py:245-283): 3 iterations at fixed
+    # connectivity, boundary vertices pinned
+    save("mesh_irregular_smoothed", iterations=3, **mesh_arrays(irregular.smooth(3)))
 
     # a polygon with holes, meshed by the product's own mesher (the reference's shape of
     # tdgl/test/conftest.py:7-49: 10x10 box united with a 30x4 strip, two round holes); the
@@ -303,6 +306,8 @@ def main():
     ppts, ptri = polygon_mesh(film, holes, max_edge_length=0.8)
     save("mesh_polygon", film=film, hole0=holes[0], hole1=holes[1],
          **mesh_arrays(RefMesh.from_triangulation(ppts, ptri)))
+    if "--meshes-only" in sys.argv:
+        return
 
     # ---- (2) operators --------------------------------------------------------------
     A = uniform_field_A(small, 0.3)

@@ -210,6 +210,24 @@ def test_polygon_mesher_with_holes_is_boundary_conforming():
     assert not Polygon("c", points=circle(1.4, center=(-2.5, 0))).contains_points(mesh.sites).any()
 
 
+def test_make_mesh_with_smoothing_keeps_boundary_and_topology():
+    from tdgl_amd import Device, Layer, Polygon
+    from tdgl_amd.geometry import box, circle
+
+    layer = Layer(coherence_length=0.5, london_lambda=2.0, thickness=0.1)
+    mk = lambda: Device("d", layer=layer, film=Polygon("film", points=box(8, 5)),  # noqa: E731
+                        holes=[Polygon("h", points=circle(1.0, center=(1.0, 0.3)))])
+    plain, smooth = mk(), mk()
+    plain.make_mesh(max_edge_length=0.4)
+    smooth.make_mesh(max_edge_length=0.4, smooth=3)
+    a, b = plain.mesh, smooth.mesh
+    assert np.array_equal(a.elements, b.elements) and np.array_equal(a.boundary_indices, b.boundary_indices)
+    assert np.array_equal(a.sites[a.boundary_indices], b.sites[b.boundary_indices])
+    interior = np.setdiff1d(np.arange(len(a.sites)), a.boundary_indices)
+    assert np.abs(a.sites[interior] - b.sites[interior]).max() > 1e-4
+    assert b.edge_mesh.dual_edge_lengths.min() >= 0 and b.areas.min() > 0
+
+
 # ---------------------------------------------------------------- reordering and AMG set-up
 def test_rcm_permutation_reduces_bandwidth():
     from tdgl_amd.hipcore import rcm_permutation

@@ -27,7 +27,8 @@ from oracle import FVOperators, OracleSolver, psi_update, run_time_loop
 
 
 # ---------------------------------------------------------------- mesh construction
-@pytest.mark.parametrize("name", ["mesh_small", "mesh_strip", "mesh_irregular", "mesh_polygon"])
+@pytest.mark.parametrize("name", ["mesh_small", "mesh_strip", "mesh_irregular", "mesh_polygon",
+                                  "mesh_irregular_smoothed"])
 def test_vectorised_mesh_matches_reference(name):
     g = load_golden(name)
     mesh = mesh_from_golden(g)
@@ -44,6 +45,18 @@ def test_vectorised_mesh_matches_reference(name):
     assert max_abs(em.dual_edge_lengths, g["mesh_dual_edge_lengths"]) < 1e-13
     # Voronoi areas: reference = per-site ConvexHull, here = signed kites
     assert max_abs(mesh.areas, g["mesh_areas"]) < 1e-13 * max(1.0, g["mesh_areas"].max())
+
+
+def test_laplacian_smoothing_matches_reference():
+    """`Mesh.smooth` (finite_volume/mesh.py:245-283): same vertex positions, and -- the smoothed
+    connectivity has obtuse boundary triangles -- the reference's hull-based cell areas."""
+    g = load_golden("mesh_irregular_smoothed")
+    mesh = mesh_from_golden(load_golden("mesh_irregular")).smooth(int(g["iterations"]))
+    assert max_abs(mesh.sites, g["mesh_sites"]) < 1e-15
+    assert np.array_equal(mesh.elements, g["mesh_elements"])
+    assert max_abs(mesh.areas, g["mesh_areas"]) < 1e-13
+    assert abs(g["mesh_areas"].sum() - 100.0) > 0.1  # the reference's cells overlap here; reproduced
+    assert max_abs(mesh.edge_mesh.dual_edge_lengths, g["mesh_dual_edge_lengths"]) < 1e-13
 
 
 def test_synthetic_generator_is_the_survey_recipe():
