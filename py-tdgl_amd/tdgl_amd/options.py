@@ -8,8 +8,9 @@ Differences, all at the backend seam:
   ``sparse_solver`` selects the AMG-preconditioned CG solve that replaces the reference's
   sparse LU, and ``gpu`` has no effect (there is no CPU path to fall back to);
 * ``pcg_rtol`` / ``pcg_max_iter`` / ``amg_smoothing_sweeps`` control that solve;
-* ``output_file`` / ``monitor`` need h5py and the reference's viewer, which are out of
-  scope: results are returned in memory (see ``tdgl_amd.solution.Solution``).
+* results are returned in memory (``tdgl_amd.solution.Solution``); ``output_file`` additionally
+  writes them in the reference's HDF5 layout at the end of the run (`tdgl_amd/io.py`, needs
+  h5py); ``monitor`` (the reference's live viewer) is accepted and ignored.
 """
 
 from dataclasses import dataclass
@@ -42,7 +43,7 @@ class SolverOptions:
     adaptive_window: int = 10  # number of recent steps averaged by the dt controller
     max_solve_retries: int = 10  # dt reductions allowed within one step
     adaptive_time_step_multiplier: float = 0.25  # dt factor per retry, in (0, 1)
-    output_file: Union[str, None] = None  # accepted, unused (results stay in memory)
+    output_file: Union[str, None] = None  # HDF5 file in the reference's layout (needs h5py)
     terminal_psi: Union[float, complex, None] = 0.0  # psi pinned on terminal sites; None = free
     gpu: bool = False  # accepted, no effect: the HIP path is the only path
     sparse_solver: Union[SparseSolver, str] = SparseSolver.SUPERLU  # any value -> AMG-PCG

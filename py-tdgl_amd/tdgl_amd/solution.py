@@ -59,6 +59,15 @@ class Solution:
     total_seconds: float = 0.0
     stats: Dict[str, float] = field(default_factory=dict)
     solve_step: int = -1
+    dynamic_vector_potential: bool = False
+    dynamic_epsilon: bool = False
+
+    def to_hdf5(self, file) -> None:
+        """Write the saved steps in the reference's DataHandler layout (`tdgl_amd.io`); ``file``
+        is a path (needs h5py) or an open h5py-like group."""
+        from .io import write_solution_h5
+
+        write_solution_h5(self, file, self.dynamic_vector_potential, self.dynamic_epsilon)
 
     @property
     def tdgl_data(self) -> TDGLData:

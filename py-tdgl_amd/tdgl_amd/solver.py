@@ -451,11 +451,13 @@ class TDGLSolver:
             pcg_iterations=cat(dyn["iters"]),
             screening_iterations=cat(dyn["scr"]) if self.screening is not None else None,
         )
-        return Solution(
+        solution = Solution(
             device=self.device,
             options=opts,
             saved_steps=saved,
             dynamics=dynamics,
+            dynamic_vector_potential=self.dynamic_vector_potential,
+            dynamic_epsilon=self.dynamic_epsilon,
             applied_vector_potential=self.applied_vector_potential,
             terminal_currents=self.terminal_currents,
             disorder_epsilon=self.disorder_epsilon,
@@ -466,6 +468,9 @@ class TDGLSolver:
                 mean_pcg_iterations=float(dynamics.pcg_iterations.mean()) if len(dynamics.pcg_iterations) else 0.0,
             ),
         )
+        if opts.output_file is not None:  # the reference streams into this file; here: at the end
+            solution.to_hdf5(opts.output_file)
+        return solution
 
 
 def solve(

@@ -228,6 +228,64 @@ def test_make_mesh_with_smoothing_keeps_boundary_and_topology():
     assert b.edge_mesh.dual_edge_lengths.min() >= 0 and b.areas.min() > 0
 
 
+# ---------------------------------------------------------------- HDF5 layout (no h5py needed)
+class _FakeGroup(dict):
+    """Minimal stand-in for an h5py group: nested dict + attrs."""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def create_group(self, name):
+        g = _FakeGroup()
+        self[name] = g
+        return g
+
+
+def test_solution_is_written_in_the_reference_hdf5_layout():
+    """Group / dataset / attribute names of `DataHandler` (tdgl/solver/runner.py:104-183) and of
+    the mesh groups (mesh.py:345-368, edge_mesh.py:94-105); running_state buffers as
+    `RunningState` exports them (runner.py:186-221)."""
+    from types import SimpleNamespace
+
+    from tdgl_amd.solution import DynamicsData, Solution, TDGLData
+
+    mesh = synthetic_mesh(6)
+    n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
+    rng = np.random.default_rng(0)
+    steps = [0, 4, 8, 10]  # save_every = 4, final partial save at step 10
+    dt = 0.1 + 0.01 * np.arange(11)
+    mu_p, th_p = rng.normal(size=(2, 11)), rng.normal(size=(2, 11))
+    saved = [TDGLData(k, float(dt[:k].sum()), float(dt[max(k - 1, 0)]), rng.normal(size=n) + 1j, rng.normal(size=n),
+                      rng.normal(size=m), rng.normal(size=m), applied_vector_potential=np.ones((m, 2)),
+                      epsilon=np.ones(n)) for k in steps]
+    sol = Solution(device=SimpleNamespace(mesh=mesh), options=SimpleNamespace(save_every=4), saved_steps=saved,
+                   dynamics=DynamicsData(dt=dt, time=np.cumsum(dt) - dt, mu=mu_p, theta=th_p))
+    f = _FakeGroup()
+    sol.to_hdf5(f)
+    assert set(f) == {"mesh", "data", "applied_vector_potential", "epsilon"}
+    assert set(f["mesh"]) == {"sites", "elements", "boundary_indices", "areas", "edge_mesh", "dual_sites"}
+    assert set(f["mesh"]["edge_mesh"]) == {"centers", "edges", "boundary_edge_indices", "directions",
+                                            "edge_lengths", "dual_edge_lengths"}
+    assert list(f["data"]) == ["0", "1", "2", "3"]
+    g2 = f["data"]["2"]
+    assert set(g2) == {"psi", "mu", "supercurrent", "normal_current", "induced_vector_potential", "running_state"}
+    assert set(g2.attrs) == {"timestamp", "step", "time", "dt"} and g2.attrs["step"] == 8
+    assert g2["induced_vector_potential"].shape == (m, 2)
+    # save 0 carries the empty buffer; save k the steps since save k-1
+    rs = [f["data"][str(k)]["running_state"] for k in range(4)]
+    assert np.all(rs[0]["dt"] == 0) and rs[0]["mu"].shape == (2, 4)
+    assert np.array_equal(rs[1]["dt"], dt[0:4]) and np.array_equal(rs[2]["mu"], mu_p[:, 4:8])
+    # (the save after the loop also holds the step that ended it, runner.py:429-453)
+    assert np.array_equal(rs[3]["dt"], np.concatenate([dt[8:11], [0]]))
+    assert np.array_equal(rs[3]["theta"][:, :3], th_p[:, 8:11])
+    # time-dependent inputs go into every step group instead of the file root
+    f = _FakeGroup()
+    sol.dynamic_vector_potential = sol.dynamic_epsilon = True
+    sol.to_hdf5(f)
+    assert set(f) == {"mesh", "data"} and {"applied_vector_potential", "epsilon"} <= set(f["data"]["1"])
+
+
 # ---------------------------------------------------------------- reordering and AMG set-up
 def test_rcm_permutation_reduces_bandwidth():
     from tdgl_amd.hipcore import rcm_permutation
