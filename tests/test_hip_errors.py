@@ -1,0 +1,130 @@
+"""GPU tests of the C ABI's error behaviour and of degenerate inputs: every failure comes back
+as a status + message (ValueError for bad arguments / call order, RuntimeError otherwise), never
+as a crash, and the smallest possible meshes run."""
+
+import copy
+
+import numpy as np
+import pytest
+
+from helpers import GAMMA_DEFAULT, U_DEFAULT, max_abs, remove_mean, synthetic_mesh, uniform_field_A
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(mesh, **kw):
+    from tdgl_amd.hipcore import TDGLContext
+
+    return TDGLContext(mesh, **kw)
+
+
+def test_invalid_meshes_are_rejected_with_a_message():
+    mesh = synthetic_mesh(6)
+    bad = copy.deepcopy(mesh)
+    bad.edge_mesh.edges = bad.edge_mesh.edges.copy()
+    bad.edge_mesh.edges[3, 1] = len(mesh.sites) + 5
+    with pytest.raises(ValueError, match=r"edge 3 has invalid sites"):
+        _ctx(bad, reorder="none")  # (the RCM ordering of the host layer would already choke on it)
+    bad = copy.deepcopy(mesh)
+    bad.edge_mesh.edge_lengths = bad.edge_mesh.edge_lengths.copy()
+    bad.edge_mesh.edge_lengths[0] = 0.0
+    with pytest.raises(ValueError, match="non-positive length"):
+        _ctx(bad)
+    with pytest.raises(ValueError):
+        _ctx(mesh, fixed_sites=[len(mesh.sites) + 1])
+
+
+def test_call_order_and_shapes():
+    mesh = synthetic_mesh(8)
+    ctx = _ctx(mesh)
+    n, m = ctx.n, ctx.m
+    with pytest.raises(RuntimeError, match="no AMG hierarchy"):
+        ctx.poisson_solve(np.zeros(n))
+    ctx.build_poisson()
+    ctx.set_state(np.ones(n, dtype=complex), np.zeros(n))
+    with pytest.raises(RuntimeError, match="set link exponents, epsilon and state first"):
+        ctx.run(1)
+    with pytest.raises(ValueError, match="Unexpected shape for vector_potential"):
+        ctx.set_link_exponents(np.zeros((m + 1, 2)))
+    with pytest.raises(RuntimeError, match="call tdgl_set_link_exponents first"):
+        ctx.update_link_exponents(np.zeros((m, 2)), 1e-3)
+    ctx.set_link_exponents(np.zeros((m, 2)))
+    with pytest.raises(ValueError, match="dt_prev must be > 0"):
+        ctx.update_link_exponents(np.zeros((m, 2)), 0.0)
+    with pytest.raises(RuntimeError, match="screening is not enabled"):
+        ctx.set_induced_vector_potential(np.zeros((m, 2)))
+    with pytest.raises(ValueError, match="has no coarse-level transfer"):
+        ctx._chk(ctx._lib.tdgl_poisson_set_fused_level(ctx._ctx, 0, None, None, None, None, None, None, None))
+    with pytest.raises(ValueError, match="screening_step_drag must be in"):
+        ctx.set_screening(mesh.sites, mesh.edge_mesh.centers, mesh.areas, step_drag=0.0)
+    ctx.close()
+
+
+def test_poisson_iteration_budget_is_reported():
+    mesh = synthetic_mesh(40)
+    ctx = _ctx(mesh)
+    ctx.build_poisson(rtol=1e-13, max_iter=2)
+    rhs = np.random.default_rng(0).normal(size=ctx.n)
+    rhs -= (rhs * mesh.areas).sum() / mesh.areas.sum()
+    with pytest.raises(RuntimeError, match=r"Poisson solve did not converge: relative residual .* after 2 iterations"):
+        ctx.poisson_solve(rhs)
+    ctx.set_poisson_options(rtol=1e-10, max_iter=200)
+    mu, iters, relres = ctx.poisson_solve(rhs)
+    assert relres <= 1e-10 and iters > 2
+    ctx.close()
+
+
+def test_inconsistent_halo_plan_is_rejected():
+    from tdgl_amd.partition import build_local_problem, rcb_partition
+
+    mesh = synthetic_mesh(20)
+    part = rcb_partition(mesh.sites, 2)
+    lp = build_local_problem(mesh, part, 0)
+    ctx = _ctx(lp.mesh, n_owned=lp.n_own)
+    wrong = copy.deepcopy(lp)
+    nb = wrong.neighbors[0]
+    a, b = wrong.recv_range[nb]
+    wrong.recv_range[nb] = (a, b - 1)  # one ghost short
+    with pytest.raises(ValueError, match="ghost sites"):
+        ctx.set_halo_plan(wrong)
+    ctx.set_halo_plan(lp)
+    assert ctx.comm_overlap()[1] % 256 == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["two_triangles", "one_triangle"])
+def test_smallest_meshes_run(shape):
+    """4 sites / 5 edges and 3 sites / 3 edges: every site on the boundary, single-level
+    hierarchy (dense coarse solve only), one SELL slice with 60 padded lanes.  The reference
+    cannot serve as the checker here (SuperLU reports "Factor is exactly singular" for the
+    pure-Neumann matrix at this size), so the step is checked through its defining equations,
+    built from the oracle's operator matrices."""
+    from oracle.fv_operators import divergence_matrix, gradient_matrix, laplacian_matrix
+    from tdgl_amd import SolverOptions, TDGLSolver
+    from tdgl_amd.finite_volume import Mesh
+
+    if shape == "two_triangles":
+        pts = np.array([[0.0, 0.0], [1.0, 0.05], [0.55, 0.8], [1.5, 0.9]])
+        tri = np.array([[0, 1, 2], [1, 3, 2]])
+    else:
+        pts = np.array([[0.0, 0.0], [1.0, 0.0], [0.45, 0.75]])
+        tri = np.array([[0, 1, 2]])
+    mesh = Mesh.from_triangulation(pts, tri)
+    assert mesh.edge_mesh.dual_edge_lengths.min() > 0
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-3, dt_max=1e-1, save_every=10**9, pcg_rtol=1e-13)
+    solver = TDGLSolver.from_dimensionless(mesh, opts, uniform_field_A(mesh, 0.7), 0.8, U_DEFAULT, GAMMA_DEFAULT)
+    ctx = solver.ctx
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    res = ctx.run(30)
+    got = ctx.get_state()
+    assert len(res["dt"]) == 30 and np.all(res["pcg_iters"] <= 2)
+    assert np.all(np.isfinite(got["psi"])) and 0.5 < np.abs(got["psi"]).min() <= np.abs(got["psi"]).max() <= 1.0
+    # mu solves L mu = div J_s (solver.py:507-516) and J_n = -grad mu (solver.py:519)
+    lap, _ = laplacian_matrix(mesh)
+    rhs = divergence_matrix(mesh) @ got["supercurrent"]
+    assert max_abs(lap @ got["mu"], rhs) < 1e-10 * max(1.0, np.abs(rhs).max())
+    assert max_abs(got["normal_current"], -(gradient_matrix(mesh) @ got["mu"])) < 1e-12
+    assert abs(got["mu"].mean()) < 1e-12
+    # total current is divergence free
+    assert max_abs(divergence_matrix(mesh) @ (got["supercurrent"] + got["normal_current"]), 0 * rhs) < 1e-9
