@@ -197,6 +197,21 @@ int tdgl_set_link_exponents(tdgl_ctx *ctx, const double *A);
  * J_n of the following tdgl_run step (solver.py:508-510, 519), recomputes the link variables
  * (operators.py:346-383) and makes A_new the new A_prev. */
 int tdgl_update_link_exponents(tdgl_ctx *ctx, const double *A_new, double dt_prev);
+/* The common special case A(t) = f(t) * A_base (a time-dependent factor times a static field, e.g.
+ * tdgl/sources/scaling.py LinearRamp * tdgl/sources/constant.py ConstantField -- the reference's
+ * flagship field-ramp example) without re-uploading A every step:
+ *   tdgl_set_link_exponents_base  uploads A_base [n_edges, 2] once and sets A = scale * A_base
+ *                                 (static semantics: dA/dt = 0, like tdgl_set_link_exponents);
+ *   tdgl_update_link_scale        A <- scale * A_base with dA/dt from the previous A, exactly
+ *                                 tdgl_update_link_exponents(scale * A_base, dt_prev);
+ *   tdgl_set_link_ramp            lets tdgl_run evaluate the factor itself before every step:
+ *                                 f(t) = initial + (final - initial) * clip((t - tmin)/(tmax - tmin), 0, 1)
+ *                                 (LinearRamp), with dt_prev = Runner.dt; on = 0 switches it off.
+ *   tdgl_get_link_scale           the factor of the current A (for saving A_applied). */
+int tdgl_set_link_exponents_base(tdgl_ctx *ctx, const double *A_base, double scale);
+int tdgl_update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev);
+int tdgl_set_link_ramp(tdgl_ctx *ctx, int32_t on, double tmin, double tmax, double initial, double final_value);
+int tdgl_get_link_scale(tdgl_ctx *ctx, double *scale);
 /* self.epsilon (solver.py:191-216, 645-648). */
 int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon);
 /* self.mu_boundary (solver.py:289, 325-345): indexed by position in boundary_edge_indices. */

@@ -463,6 +463,8 @@ static void refresh_ceff(tdgl_ctx *ctx) {
                        ctx->cvec.p, ctx->ceff.p);
 }
 
+static int update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev);  // below
+
 #include "comm.inc"
 #include "poisson.inc"
 #include "screening.inc"
@@ -481,35 +483,117 @@ extern "C" int tdgl_update_link_exponents(tdgl_ctx *ctx, const double *A_new, do
     return set_links_impl(ctx, A_new, true, dt_prev);
 }
 
-static int set_links_impl(tdgl_ctx *ctx, const double *A, bool dynamic, double dt_prev) {
-    CTX_GUARD(ctx);
-    if (!A) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_link_exponents: null A");
+// everything that follows new values in ctx->e_A: dA/dt (dynamic) or A_prev <- A (static), the
+// rhs term of dA/dt, link variables, covariant-Laplacian values
+static int finish_links(tdgl_ctx *ctx, bool dynamic, double dt_prev) {
+    const size_t bytes = 2 * ctx->m_pad * sizeof(double);
+    const int32_t *only_if = nullptr;
+    if (dynamic) {
+        const int nblk = grid_for(ctx->m);
+        if (ctx->link_block_changed.n == 0) {
+            HIP_TRY(ctx, ctx->link_block_changed.alloc(nblk));
+            HIP_TRY(ctx, ctx->link_changed.alloc(1));
+        }
+        hipLaunchKernelGGL(k_dadt, dim3(nblk), dim3(BLOCK), 0, ctx->stream, ctx->m, 1.0 / dt_prev,
+                           ctx->e_A.p, ctx->e_Aprev.p, ctx->e_dirx.p, ctx->e_diry.p, ctx->e_inv_len.p, ctx->e_dAdt.p,
+                           ctx->link_block_changed.p);
+        hipLaunchKernelGGL(k_any_flag, dim3(1), dim3(BLOCK), 0, ctx->stream, nblk, ctx->link_block_changed.p,
+                           ctx->link_changed.p);
+        // (with screening the links are rebuilt from A_applied + A_induced in every screening
+        // iteration anyway, solver.py:670-673)
+        only_if = ctx->link_changed.p;
+        ctx->has_dadt = true;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->e_Aprev.p, ctx->e_A.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->has_dadt = false;
+    }
+    refresh_ceff(ctx);
+    hipLaunchKernelGGL(k_link_variables, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m,
+                       ctx->e_A.p, ctx->scr_enabled ? ctx->scr_Aind.p : (const double *)nullptr, ctx->e_dirx.p,
+                       ctx->e_diry.p, ctx->e_U.p, only_if);
+    hipLaunchKernelGGL(k_fill_laplacian, dim3(grid_for(ctx->lap_pat.n_slots)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->lap_pat.n_slots, ctx->lap_slot_edge.p, ctx->lap_slot_w.p, ctx->e_U.p, ctx->lap_vals.p,
+                       only_if);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->have_links = true;
+    ctx->lap_valid = false;
+    ctx->currents_valid = false;
+    return TDGL_OK;
+}
+
+static int upload_edge_vectors(tdgl_ctx *ctx, const double *A, double *dst) {
     std::vector<double> tmp(2 * ctx->m_pad, 0.0);
     for (int64_t k = 0; k < ctx->m; ++k) {
         const int32_t e = ctx->edge_perm[k];
         tmp[2 * k] = A[2 * e];
         tmp[2 * k + 1] = A[2 * e + 1];
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->e_A.p, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (dynamic) {
-        hipLaunchKernelGGL(k_dadt, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m, 1.0 / dt_prev,
-                           ctx->e_A.p, ctx->e_Aprev.p, ctx->e_dirx.p, ctx->e_diry.p, ctx->e_inv_len.p, ctx->e_dAdt.p);
-        ctx->has_dadt = true;
-    } else {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->e_Aprev.p, ctx->e_A.p, tmp.size() * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        ctx->has_dadt = false;
-    }
-    refresh_ceff(ctx);
-    hipLaunchKernelGGL(k_link_variables, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m,
-                       ctx->e_A.p, ctx->scr_enabled ? ctx->scr_Aind.p : (const double *)nullptr, ctx->e_dirx.p,
-                       ctx->e_diry.p, ctx->e_U.p);
-    hipLaunchKernelGGL(k_fill_laplacian, dim3(grid_for(ctx->lap_pat.n_slots)), dim3(BLOCK), 0, ctx->stream,
-                       ctx->lap_pat.n_slots, ctx->lap_slot_edge.p, ctx->lap_slot_w.p, ctx->e_U.p, ctx->lap_vals.p);
-    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // tmp goes out of scope
+    return TDGL_OK;
+}
+
+static int set_links_impl(tdgl_ctx *ctx, const double *A, bool dynamic, double dt_prev) {
+    CTX_GUARD(ctx);
+    if (!A) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_link_exponents: null A");
+    TDGL_TRY(upload_edge_vectors(ctx, A, ctx->e_A.p));
+    ctx->ramp_on = false;
+    TDGL_TRY(finish_links(ctx, dynamic, dt_prev));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->have_links = true;
-    ctx->lap_valid = false;
-    ctx->currents_valid = false;
+    return TDGL_OK;
+}
+
+// ---- A(t) = scale(t) * A_base without leaving the device ---------------------------------------
+extern "C" int tdgl_set_link_exponents_base(tdgl_ctx *ctx, const double *A_base, double scale) {
+    CTX_GUARD(ctx);
+    if (!A_base) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_link_exponents_base: null A_base");
+    if (ctx->e_Abase.n == 0) HIP_TRY(ctx, ctx->e_Abase.alloc(2 * ctx->m_pad));
+    TDGL_TRY(upload_edge_vectors(ctx, A_base, ctx->e_Abase.p));
+    ctx->have_base = true;
+    ctx->ramp_on = false;
+    hipLaunchKernelGGL(k_scale_links, dim3(grid_for(2 * ctx->m_pad)), dim3(BLOCK), 0, ctx->stream, 2 * ctx->m_pad,
+                       scale, ctx->e_Abase.p, ctx->e_A.p);
+    ctx->link_scale = ctx->link_scale_prev = scale;
+    TDGL_TRY(finish_links(ctx, false, 0.0));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TDGL_OK;
+}
+
+static int update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev) {
+    // nothing moves when the factor has been constant over the last two evaluations (A and
+    // dA/dt = 0 are already in place)
+    if (scale == ctx->link_scale && scale == ctx->link_scale_prev && ctx->has_dadt) return TDGL_OK;
+    hipLaunchKernelGGL(k_scale_links, dim3(grid_for(2 * ctx->m_pad)), dim3(BLOCK), 0, ctx->stream, 2 * ctx->m_pad,
+                       scale, ctx->e_Abase.p, ctx->e_A.p);
+    ctx->link_scale_prev = ctx->link_scale;
+    ctx->link_scale = scale;
+    return finish_links(ctx, true, dt_prev);
+}
+
+extern "C" int tdgl_update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev) {
+    CTX_GUARD(ctx);
+    if (!ctx->have_base) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "call tdgl_set_link_exponents_base first");
+    if (!(dt_prev > 0.0)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_update_link_scale: dt_prev must be > 0");
+    TDGL_TRY(update_link_scale(ctx, scale, dt_prev));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_link_ramp(tdgl_ctx *ctx, int32_t on, double tmin, double tmax, double initial, double final_) {
+    CTX_GUARD(ctx);
+    if (on && !ctx->have_base) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "call tdgl_set_link_exponents_base first");
+    if (on && !(tmax > tmin)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_link_ramp: tmax must be > tmin");
+    ctx->ramp_on = on != 0;
+    ctx->ramp_tmin = tmin;
+    ctx->ramp_tmax = tmax;
+    ctx->ramp_initial = initial;
+    ctx->ramp_final = final_;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_get_link_scale(tdgl_ctx *ctx, double *scale) {
+    if (!ctx || !scale) return TDGL_ERR_ARG;
+    *scale = ctx->link_scale;
     return TDGL_OK;
 }
 

@@ -167,6 +167,13 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> e_A, e_Aprev;    // link exponents now / at the previous step [2 * m_pad]
     tdgl::DevBuf<double> e_dAdt;          // dA/dt along the edges (time-dependent A), else unused
     bool has_dadt = false;
+    tdgl::DevBuf<int32_t> link_block_changed, link_changed;  // allclose(new_A, old_A) test (k_dadt)
+    // A(t) = scale(t) * A_base on the device (tdgl_set_link_exponents_base / _scale / _ramp)
+    tdgl::DevBuf<double> e_Abase;
+    bool have_base = false;
+    bool ramp_on = false;
+    double ramp_tmin = 0.0, ramp_tmax = 1.0, ramp_initial = 0.0, ramp_final = 1.0;
+    double link_scale = 1.0, link_scale_prev = 1.0;  // scale of the current / previous A
     // boundary term: c = mu_boundary_laplacian @ mu_boundary
     tdgl::DevBuf<int32_t> b_s0, b_s1;
     tdgl::DevBuf<double> b_c0, b_c1, b_mu;

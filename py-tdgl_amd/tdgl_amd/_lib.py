@@ -141,6 +141,10 @@ SIGNATURES = {
     "tdgl_set_comm_overlap": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_get_comm_overlap": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "tdgl_set_link_exponents": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_set_link_exponents_base": (C.c_int, [_CTX, c_f64p, C.c_double]),
+    "tdgl_update_link_scale": (C.c_int, [_CTX, C.c_double, C.c_double]),
+    "tdgl_set_link_ramp": (C.c_int, [_CTX, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "tdgl_get_link_scale": (C.c_int, [_CTX, c_f64p]),
     "tdgl_update_link_exponents": (C.c_int, [_CTX, c_f64p, C.c_double]),
     "tdgl_set_epsilon": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_mu_boundary": (C.c_int, [_CTX, c_f64p]),

@@ -287,6 +287,27 @@ class TDGLContext:
             raise ValueError(f"Unexpected shape for vector_potential: {A_new.shape}.")
         self._chk(self._lib.tdgl_update_link_exponents(self._ctx, p_f64(A_new), float(dt_prev)))
 
+    def set_link_exponents_base(self, A_base, scale=1.0):
+        """A = scale * A_base, A_base kept on the device (static semantics: dA/dt = 0)."""
+        A_base = f64(A_base)
+        if A_base.shape != (self.m, 2):
+            raise ValueError(f"Unexpected shape for vector_potential: {A_base.shape}.")
+        self._chk(self._lib.tdgl_set_link_exponents_base(self._ctx, p_f64(A_base), float(scale)))
+
+    def update_link_scale(self, scale, dt_prev):
+        """A <- scale * A_base with dA/dt from the previous A (no upload)."""
+        self._chk(self._lib.tdgl_update_link_scale(self._ctx, float(scale), float(dt_prev)))
+
+    def set_link_ramp(self, tmin, tmax, initial, final, on=True):
+        """Let ``run`` evaluate A(t) = LinearRamp(t) * A_base itself before every step."""
+        self._chk(self._lib.tdgl_set_link_ramp(self._ctx, int(bool(on)), float(tmin), float(tmax),
+                                               float(initial), float(final)))
+
+    def link_scale(self):
+        v = C.c_double(0)
+        self._chk(self._lib.tdgl_get_link_scale(self._ctx, C.byref(v)))
+        return v.value
+
     def set_epsilon(self, eps):
         eps = f64(np.broadcast_to(eps, (self.n,)))
         self._chk(self._lib.tdgl_set_epsilon(self._ctx, p_f64(eps)))

@@ -23,8 +23,22 @@ class Parameter:
         self.func = func
         self.kwargs = kwargs
         self.time_dependent = _takes_time(func)
+        # True for factors that do not depend on position (e.g. LinearRamp): lets the solver
+        # recognise A(t) = f(t) * A_static and keep A_static on the device
+        self.uniform_in_space = False
+        self.ramp = None  # LinearRamp: dict(tmin, tmax, initial, final)
         if "t" in kwargs:
             raise ValueError("'t' cannot be bound as a Parameter keyword argument.")
+
+    def separable_product(self):
+        """``(f, static)`` if this parameter is ``f(t) * static(x, y, z)`` with ``f`` uniform in
+        space and ``static`` independent of time, else ``None``."""
+        return None
+
+    def scalar(self, t) -> float:
+        """Value of a uniform-in-space factor at time ``t``."""
+        z = np.zeros(1)
+        return float(np.ravel(self(z, z, z, t=t))[0])
 
     def __call__(self, x, y, z, t=None):
         kw = dict(self.kwargs)
@@ -77,6 +91,18 @@ class CompositeParameter(Parameter):
         self.left, self.right, self.op = left, right, op
         self.kwargs = {}
         self.time_dependent = bool(getattr(left, "time_dependent", False) or getattr(right, "time_dependent", False))
+        uniform = [(not isinstance(v, Parameter)) or v.uniform_in_space for v in (left, right)]
+        self.uniform_in_space = all(uniform)
+        self.ramp = None
+
+    def separable_product(self):
+        if self.op is not operator.mul:
+            return None
+        for f, static in ((self.left, self.right), (self.right, self.left)):
+            if (isinstance(f, Parameter) and f.uniform_in_space and f.time_dependent
+                    and isinstance(static, Parameter) and not static.time_dependent):
+                return f, static
+        return None
 
     def __call__(self, x, y, z, t=None):
         def ev(v):
@@ -116,4 +142,7 @@ def LinearRamp(tmin: float = 0, tmax: float = 10, initial: float = 0, final: flo
         frac = np.clip((t - tmin) / (tmax - tmin), 0.0, 1.0)
         return (initial + (final - initial) * frac) * np.ones_like(x, dtype=float)
 
-    return Parameter(linear_ramp, tmin=tmin, tmax=tmax, initial=initial, final=final)
+    p = Parameter(linear_ramp, tmin=tmin, tmax=tmax, initial=initial, final=final)
+    p.uniform_in_space = True
+    p.ramp = dict(tmin=float(tmin), tmax=float(tmax), initial=float(initial), final=float(final))
+    return p

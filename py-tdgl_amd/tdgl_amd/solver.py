@@ -114,7 +114,19 @@ class TDGLSolver:
         self.A_scale = device.field_scale(options.field_units)
         ex, ey = self.edge_centers[:, 0], self.edge_centers[:, 1]
         self.vector_potential_func = None
-        if self.dynamic_vector_potential:
+        self._A_base = self._A_factor = self._A_ramp = None
+        sep = applied_vector_potential.separable_product() if (
+            self.dynamic_vector_potential and hasattr(applied_vector_potential, "separable_product")) else None
+        if sep is not None:
+            # A(t) = f(t) * A_static (the reference's field-ramp example): A_static stays on the
+            # device, the factor is evaluated per step -- by tdgl_run itself for a LinearRamp
+            factor, static = sep
+            self._A_base = self.A_scale * np.asarray(static(ex, ey, self.z0))[:, :2]
+            self._A_factor = factor.scalar
+            self._A_ramp = factor.ramp
+            self.vector_potential_func = lambda t: factor.scalar(t) * self._A_base
+            A = self.vector_potential_func(0)
+        elif self.dynamic_vector_potential:
             # solver.py:347-362: A(t) on the edge centres, scaled to dimensionless units
             def vector_potential_func(t):
                 return self.A_scale * np.asarray(applied_vector_potential(ex, ey, self.z0, t=t))[:, :2]
@@ -198,14 +210,16 @@ class TDGLSolver:
                            u: float = 5.79, gamma: float = 10.0, terminal_info=(),
                            current_func=None, probe_points=None, device=None,
                            vector_potential_func=None, epsilon_func=None,
-                           screening=None) -> "TDGLSolver":
+                           screening=None, vector_potential_ramp=None) -> "TDGLSolver":
         """Build a solver directly from dimensionless inputs -- the arrays the reference's
         ``__init__`` ends up with (solver.py:185, 214, 225, 254-256): ``A[m, 2]``,
         ``epsilon[n]``, ``TerminalInfo`` records and ``t -> {name: dimensionless current}``.
         Used by the parity tests and the benchmark, whose configurations are stated in
         dimensionless form (b = B/Bc2, xi = 1).  ``screening``: ``{sites, edge_centers, areas}``
         (areas already multiplied by the kernel prefactor, solver.py:307-309); requires
-        ``options.include_screening``."""
+        ``options.include_screening``.  ``vector_potential_ramp``: ``(A_base[m, 2], dict(tmin, tmax,
+        initial, final))`` for ``A(t) = LinearRamp(t) * A_base`` evaluated by the library itself
+        (then ``link_exponents`` must be its value at t = 0)."""
         self = object.__new__(cls)
         options.validate()
         self.device = device
@@ -220,6 +234,15 @@ class TDGLSolver:
         self.disorder_epsilon = epsilon
         # optional time dependence: t -> A[m, 2] / t -> epsilon[n], already dimensionless
         self.vector_potential_func = vector_potential_func
+        self._A_base = self._A_factor = self._A_ramp = None
+        if vector_potential_ramp is not None:
+            from .parameter import LinearRamp
+
+            base, ramp = vector_potential_ramp
+            factor = LinearRamp(**ramp)
+            self._A_base = np.asarray(base, dtype=float)
+            self._A_factor, self._A_ramp = factor.scalar, factor.ramp
+            self.vector_potential_func = vector_potential_func = lambda t: factor.scalar(t) * self._A_base
         self.epsilon_func = epsilon_func
         self.dynamic_vector_potential = vector_potential_func is not None
         self.dynamic_epsilon = epsilon_func is not None
@@ -273,8 +296,13 @@ class TDGLSolver:
             edge_currents_every_step=options.edge_currents_every_step,
         )
         self.operators.build_operators()
-        self.operators.set_link_exponents(self.current_A_applied)
         self.ctx = self.operators.ctx
+        if self._A_base is not None:
+            self.ctx.set_link_exponents_base(self._A_base, self._A_factor(0))
+            if self._A_ramp is not None:
+                self.ctx.set_link_ramp(**self._A_ramp)
+        else:
+            self.operators.set_link_exponents(self.current_A_applied)
 
         # ---- initial values (solver.py:284-289) ------------------------------------------------
         self.psi_init = np.ones(len(mesh.sites), dtype=np.complex128)
@@ -317,7 +345,11 @@ class TDGLSolver:
     def update_dynamic_inputs(self, time: float, dt_prev: float) -> None:
         """solver.py:626-648: re-evaluate A(t) (-> link variables and dA/dt with the previous
         step's dt) and epsilon(t) before a step."""
-        if self.dynamic_vector_potential:
+        if self._A_ramp is not None:
+            pass  # tdgl_run evaluates the ramp itself (tdgl_set_link_ramp)
+        elif self._A_base is not None:
+            self.ctx.update_link_scale(self._A_factor(time), dt_prev)
+        elif self.dynamic_vector_potential:
             self.current_A_applied = np.asarray(self.vector_potential_func(time), dtype=float)
             self.ctx.update_link_exponents(self.current_A_applied, dt_prev)
         if self.dynamic_epsilon:
@@ -360,6 +392,8 @@ class TDGLSolver:
         else:
             a_ind = np.zeros((self.num_edges, 2)) if induced_vector_potential is None else induced_vector_potential
         extra = []
+        if self._A_base is not None:
+            self.current_A_applied = ctx.link_scale() * self._A_base
         if self.dynamic_vector_potential:
             extra.append(self.current_A_applied)
         if self.dynamic_epsilon:
@@ -402,6 +436,8 @@ class TDGLSolver:
                 st = ctx.get_state()
                 js, jn = st["supercurrent"], st["normal_current"]
             a_ind = ctx.induced_vector_potential() if self.screening is not None else None
+            if self._A_base is not None:
+                self.current_A_applied = ctx.link_scale() * self._A_base
             saved.append(TDGLData(ls["step"], ls["time"], ls["dt"], st["psi"], st["mu"], js, jn,
                                   applied_vector_potential=self.current_A_applied, epsilon=self.epsilon,
                                   induced_vector_potential=a_ind))
@@ -412,7 +448,8 @@ class TDGLSolver:
             while True:
                 if save and i % opts.save_every == 0:
                     save_step()
-                per_step = self.dynamic_currents or self.dynamic_vector_potential or self.dynamic_epsilon
+                per_step = (self.dynamic_currents or self.dynamic_epsilon
+                            or (self.dynamic_vector_potential and self._A_ramp is None))
                 chunk = 1 if per_step else opts.save_every - (i % opts.save_every)
                 ls = ctx.loop_state()
                 self.update_mu_boundary(ls["time"] if self.dynamic_currents else 0.0)

@@ -268,7 +268,41 @@ def save(name, **arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays")
 
 
+def gen_dynamic_lag(small):
+    """(4g') A(t) = ramp(t) * A_base moving by LESS than np.allclose's tolerance per step: the
+    reference then updates dA/dt and current_A_applied but NOT the link variables
+    (solver.py:636-637), which stay at their t = 0 values for the whole run."""
+    o = SolverOptions(solve_time=2.0, dt_init=1e-3, dt_max=1e-3, adaptive=False, save_every=500)
+    probes = [small.closest_site((-5, 0)), small.closest_site((5, 0))]
+    A_base = uniform_field_A(small, 0.01)
+    ramp = dict(tmin=0.0, tmax=5.0, initial=30.0, final=31.0)
+
+    def scale(t):
+        frac = min(max((t - ramp["tmin"]) / (ramp["tmax"] - ramp["tmin"]), 0.0), 1.0)
+        return ramp["initial"] + (ramp["final"] - ramp["initial"]) * frac
+
+    def ramp_A(x, y, z, *, t=0):
+        a2 = scale(t) * A_base
+        return np.column_stack([a2, np.zeros(len(a2))])
+
+    s, psi0, _ = make_ref_solver(small, scale(0) * A_base, o, probe_points=probes)
+    s.dynamic_vector_potential = True
+    s.applied_vector_potential = ramp_A
+    s.A_scale = 1.0
+    s.edge_centers = small.edge_mesh.centers
+    s.z0 = np.zeros(len(s.edge_centers))
+    s.current_A_applied = ramp_A(None, None, None, t=0)[:, :2]
+    s.operators.set_link_exponents(s.current_A_applied)
+    out = run_reference(s, psi0, o)
+    print("dynamic-lag calls:", len(out["call_dt"]), "max |J_s|", np.abs(out["final_supercurrent"]).max())
+    save("traj_dynamic_lag", probe_points=np.array(probes), A_base=A_base,
+         **{"ramp_" + k: v for k, v in ramp.items()}, **options_arrays(o), **out)
+
+
 def main():
+    if "--dynamic-lag-only" in sys.argv:
+        gen_dynamic_lag(make_ref_mesh(20, 20))
+        return
     # ---- (1) meshes ---------------------------------------------------------------
     small = make_ref_mesh(20, 20)  # 516 sites
     strip = make_ref_mesh(60, 15)  # 1107 sites
@@ -455,6 +489,8 @@ def main():
     print("dynamic calls:", len(out["call_dt"]), "min|psi|^2", (np.abs(out["final_psi"]) ** 2).min())
     save("traj_dynamic_small", b_final=0.6, probe_points=np.array(probes), A_full=A_full,
          **options_arrays(o), **out)
+
+    gen_dynamic_lag(small)
 
     # (4h) screening (solver.py:522-578, 654-688; tdgl/solver/screening.py:12-42): the induced
     # vector potential is iterated to self-consistency inside every step.  Tiny mesh: without

@@ -347,6 +347,42 @@ def test_trajectory_time_dependent_field_and_epsilon():
     _assert_hip_trajectory(g, sol, 1e-7)  # 265 steps; measured 1e-8
 
 
+@pytest.mark.parametrize("path", ["upload_per_step", "scale_per_step", "native_ramp"])
+def test_trajectory_with_lagging_link_variables(path):
+    """A(t) = ramp(t) * A_base moving by less than np.allclose's tolerance per step: dA/dt follows,
+    the link variables stay where they were (solver.py:636-637) -- through the per-step upload,
+    the device-side scaling and the ramp evaluated inside tdgl_run."""
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    g = load_golden("traj_dynamic_lag")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    o = options_from_golden(g)
+    opts = SolverOptions(solve_time=o.solve_time, dt_init=o.dt_init, dt_max=o.dt_max, adaptive=False,
+                         save_every=o.save_every, pcg_rtol=1e-12)
+    A_base = g["A_base"]
+    ramp = {k: float(g["ramp_" + k]) for k in ("tmin", "tmax", "initial", "final")}
+
+    def scale(t):
+        frac = min(max((t - ramp["tmin"]) / (ramp["tmax"] - ramp["tmin"]), 0.0), 1.0)
+        return ramp["initial"] + (ramp["final"] - ramp["initial"]) * frac
+
+    kw = dict(probe_points=[int(p) for p in g["probe_points"]])
+    if path == "native_ramp":
+        kw["vector_potential_ramp"] = (A_base, ramp)
+    else:
+        kw["vector_potential_func"] = lambda t: scale(t) * A_base
+    solver = TDGLSolver.from_dimensionless(mesh, opts, scale(0.0) * A_base, 1.0, U_DEFAULT, GAMMA_DEFAULT, **kw)
+    if path == "scale_per_step":  # the same numbers, scaled on the device instead of uploaded
+        solver._A_base, solver._A_factor = A_base, scale
+        solver.ctx.set_link_exponents_base(A_base, scale(0.0))
+    sol = solver.solve()
+    _assert_hip_trajectory(g, sol, 1e-8)
+    # A_applied that is saved follows the ramp (value at the last step taken) although the links do not
+    assert max_abs(sol.tdgl_data.applied_vector_potential, scale(float(g["call_time"][-1])) * A_base) < 1e-12
+    if path == "native_ramp":
+        assert sol.stats["steps_simulating"] == len(g["call_dt"])
+
+
 def _screening_solver(g, mesh, **opt_override):
     from tdgl_amd import SolverOptions, TDGLSolver
 

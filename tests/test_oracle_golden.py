@@ -226,6 +226,30 @@ def test_trajectory_time_dependent_field_and_epsilon():
     _assert_trajectory(g, mesh, out, 1e-12)
 
 
+def _lag_scale(g, t):
+    frac = min(max((t - float(g["ramp_tmin"])) / (float(g["ramp_tmax"]) - float(g["ramp_tmin"])), 0.0), 1.0)
+    return float(g["ramp_initial"]) + (float(g["ramp_final"]) - float(g["ramp_initial"])) * frac
+
+
+def test_trajectory_with_lagging_link_variables():
+    """A(t) moves by less than np.allclose's tolerance per step: the reference keeps dA/dt and
+    A_applied current but never refreshes the link variables (solver.py:636-637)."""
+    g = load_golden("traj_dynamic_lag")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    opts = options_from_golden(g)
+    A_base = g["A_base"]
+    solver = OracleSolver(
+        mesh, _lag_scale(g, 0.0) * A_base, 1.0, U_DEFAULT, GAMMA_DEFAULT, opts,
+        probe_points=[int(p) for p in g["probe_points"]],
+        vector_potential_func=lambda t: _lag_scale(g, t) * A_base,
+    )
+    out = run_time_loop(solver, opts)
+    _assert_trajectory(g, mesh, out, 1e-11)
+    # the quirk matters: with links that follow A the supercurrent ends up visibly different
+    assert max_abs(solver.operators.link_exponents, _lag_scale(g, 0.0) * A_base) == 0
+    assert max_abs(solver.current_A, _lag_scale(g, 0.0) * A_base) > 1e-3
+
+
 def _hot_spot(r, t):
     c = np.array([-6.0 + 1.5 * t, 1.0])
     return 1.0 - 0.6 * np.exp(-((r - c) ** 2).sum(axis=1) / 4.0)
