@@ -66,6 +66,10 @@ def test_poisson_iteration_budget_is_reported():
     ctx.build_poisson(rtol=1e-13, max_iter=2)
     rhs = np.random.default_rng(0).normal(size=ctx.n)
     rhs -= (rhs * mesh.areas).sum() / mesh.areas.sum()
+    # (2 iterations with the fp32-stored level-0 operators + the fp64 restart's 2)
+    with pytest.raises(RuntimeError, match=r"Poisson solve did not converge: relative residual .* after 4 iterations"):
+        ctx.poisson_solve(rhs)
+    ctx.set_poisson_options(rtol=1e-13, max_iter=2, precond_fp32=False)
     with pytest.raises(RuntimeError, match=r"Poisson solve did not converge: relative residual .* after 2 iterations"):
         ctx.poisson_solve(rhs)
     ctx.set_poisson_options(rtol=1e-10, max_iter=200)
