@@ -48,7 +48,7 @@ static inline void sell_grid(int n_slices, int *per_xcd, int *grid) {
 // SELL construction from CSR (host)
 static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
                               const int32_t *indices, SellPattern &pat,
-                              std::vector<int64_t> *slot_of_nnz) {
+                              std::vector<int64_t> *slot_of_nnz, bool want16 = false) {
     pat.n_rows = n_rows;
     pat.n_pad = round_up(std::max<int64_t>(n_rows, 1), WAVE);
     pat.n_slices = (int32_t)(pat.n_pad / WAVE);
@@ -82,13 +82,34 @@ static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indp
     }
     HIP_TRY(ctx, pat.slice_off.upload(off));
     HIP_TRY(ctx, pat.cols.upload(cols));
+    pat.use16 = false;
+    if (want16 && !getenv("TDGL_NO_INDEX16")) {  // (the environment switch is for A/B measurements)
+        std::vector<int16_t> d16(pat.n_slots);
+        bool fits = true;
+        for (int sl = 0; sl < pat.n_slices && fits; ++sl)
+            for (int k = off[sl]; k < off[sl + 1] && fits; ++k)
+                for (int lane = 0; lane < WAVE; ++lane) {
+                    const int64_t slot = (int64_t)k * WAVE + lane, row = (int64_t)sl * WAVE + lane;
+                    // padded lanes past n_rows point at column 0: give them delta 0 (own row)
+                    const int64_t delta = (row < n_rows) ? (int64_t)cols[slot] - row : 0;
+                    if (delta < -32768 || delta > 32767) {
+                        fits = false;
+                        break;
+                    }
+                    d16[slot] = (int16_t)delta;
+                }
+        if (fits) {
+            HIP_TRY(ctx, pat.cols16.upload(d16));
+            pat.use16 = true;
+        }
+    }
     return TDGL_OK;
 }
 
 static int build_sell_f64(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
-                          const int32_t *indices, const double *data, SellF64 &A) {
+                          const int32_t *indices, const double *data, SellF64 &A, bool want16 = false) {
     std::vector<int64_t> slot;
-    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr, indices, A.pat, &slot));
+    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr, indices, A.pat, &slot, want16));
     std::vector<double> vals(A.pat.n_slots, 0.0);
     for (int64_t k = 0; k < indptr[n_rows]; ++k) vals[slot[k]] = data[k];
     HIP_TRY(ctx, A.vals.upload(vals));
@@ -232,7 +253,7 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     // rows exist for owned sites only; ghost sites appear as columns
     const int64_t n_rows = ctx->n_own;
     std::vector<int64_t> slot;
-    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr.data(), nbr.data(), ctx->lap_pat, &slot));
+    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr.data(), nbr.data(), ctx->lap_pat, &slot, /*want16=*/true));
     const int64_t n_slots = ctx->lap_pat.n_slots;
     std::vector<int32_t> slot_edge(n_slots, -1);
     std::vector<double> slot_w(n_slots, 0.0), diag(ctx->n_pad, 0.0), area(ctx->n_pad, 0.0);
@@ -409,16 +430,18 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
     tile_range(ctx, ctx->lap_pat.n_slices, part, &tile_base, &slice_end, &tiles);
     if (tiles <= 0) return;
     const int per_xcd = (tiles + XCDS - 1) / XCDS, grid = per_xcd * XCDS;
-    if (rhs)
-        hipLaunchKernelGGL(k_psi_laplacian<true>, dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd,
-                           tile_base, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
-                           ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
-                           ctx->ceff.p, ctx->bvec.p);
-    else
-        hipLaunchKernelGGL(k_psi_laplacian<false>, dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd,
-                           tile_base, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_pat.cols.p,
-                           ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p, psi, lap, ctx->area.p,
-                           ctx->cvec.p, ctx->bvec.p);
+    const SellPattern &pat = ctx->lap_pat;
+    const double *c = rhs ? ctx->ceff.p : ctx->cvec.p;
+#define TDGL_K1(RHS, IT, COLS)                                                                              \
+    hipLaunchKernelGGL((k_psi_laplacian<RHS, IT>), dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd, \
+                       tile_base, pat.n_rows, pat.slice_off.p, COLS, ctx->lap_vals.p, ctx->lap_diag.p,     \
+                       ctx->fixed_mask.p, psi, lap, ctx->area.p, c, ctx->bvec.p)
+    if (pat.use16) {
+        if (rhs) TDGL_K1(true, int16_t, pat.cols16.p); else TDGL_K1(false, int16_t, pat.cols16.p);
+    } else {
+        if (rhs) TDGL_K1(true, int32_t, pat.cols.p); else TDGL_K1(false, int32_t, pat.cols.p);
+    }
+#undef TDGL_K1
 }
 
 static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,

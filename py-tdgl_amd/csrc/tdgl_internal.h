@@ -69,6 +69,11 @@ struct SellPattern {
     int64_t n_slots = 0;  // slice_off[n_slices] * 64
     DevBuf<int32_t> slice_off;
     DevBuf<int32_t> cols;
+    // Square operators in RCM order: column - row fits 16 bits (the bandwidth is ~2 sqrt(n)), which
+    // halves the index stream of the kernels that run at the HBM ceiling.  Built only on request
+    // and only when every delta fits; kernels fall back to `cols` otherwise.
+    DevBuf<int16_t> cols16;
+    bool use16 = false;
 };
 
 struct SellF64 {
