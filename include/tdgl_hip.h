@@ -107,12 +107,13 @@ typedef struct {
                              in time through the last two / three solutions              */
     int32_t nu_fine;      /* smoother degree on level 0 (0 = nu).  Default 1 with nu = 2:
                              halves the level-0 passes per cycle for ~5 % more iterations  */
-    int32_t precond_fp32; /* 1 (default): the level-0 operators of the V-cycle (fused restriction,
-                             prolongation, smoothing step) are stored and streamed in fp32 and
-                             the preconditioned residual z is an fp32 vector; the CG itself
-                             (A p, residual recurrence, dot products, convergence test) and the
-                             coarse levels stay fp64, so the solution meets the same rtol.
-                             Active with nu_fine = 1 and a fused restriction on one GPU.  */
+    int32_t precond_fp32; /* 1 (default): the operators of the V-cycle (level 0: fused restriction,
+                             prolongation, smoothing step; intermediate levels: A, R, RA, AP, P)
+                             are stored and streamed in fp32 and the preconditioned residual z
+                             is an fp32 vector; arithmetic is fp64 and the CG itself (A p,
+                             residual recurrence, dot products, convergence test) uses fp64
+                             data only, so the solution meets the same rtol.  Active with
+                             nu_fine = 1 and a fused restriction on one GPU.  */
 } tdgl_poisson_options;
 
 /* ------------------------------------------------------------------ lifetime */

@@ -85,6 +85,7 @@ struct Csr {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     DevBuf<int32_t> indptr, indices;
     DevBuf<double> data;
+    DevBuf<float> data32;  // fp32 copy of the values (mixed-precision preconditioner), on demand
 };
 
 // Level 0 (rows ~ 10^6, 7 entries each) streams through SELL-64, one lane per row.  Coarse
@@ -106,6 +107,7 @@ struct AmgLevel {
     Csr RA;                          // R A   [n_coarse x n]
     Csr AP;                          // A P   [n x n_coarse]
     DevBuf<double> APp;              // P on the pattern of A P
+    DevBuf<float> APp32;
 };
 
 // scalars of the PCG recurrence, resident on the device
