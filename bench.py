@@ -41,8 +41,8 @@ B_FIELD = 0.1  # B / Bc2
 
 # HBM bytes per launch of the fused psi-Laplacian kernel from rocprofv3 PMC counters
 # ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction calibrated on a copy kernel in the same
-# run: profiles/r01f_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
-PMC_TRAFFIC_BYTES = {"1M": 188.2e6}
+# run: profiles/r01h_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
+PMC_TRAFFIC_BYTES = {"1M": 175.7e6}
 
 
 def log(*a):
@@ -268,7 +268,7 @@ def main():
         unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 4),
         traffic=PMC_TRAFFIC_BYTES.get(args.workload) if not use_dd else None,
-        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01f_pmc_hbm_traffic_1M.txt",
+        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01h_pmc_hbm_traffic_1M.txt",
         algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"],
         avg_launch_ms=round(k1_avg_ms, 5),
         launches=launches,
