@@ -203,6 +203,7 @@ struct tdgl_ctx {
     double fusedR_c = 0.0;                // the smoothing coefficient it was built for
     tdgl::DevBuf<float> fusedR32;         // its values in fp32
     bool f32_ready = false;               // fp32 copies are current
+    bool coarse32_ready = false;          // ... of the intermediate-level operators
     int64_t f32_fallbacks = 0;            // solves that had to be finished with the fp64 operators
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
