@@ -269,7 +269,8 @@ class TDGLContext:
                                 int(extrapolate), int(nu_fine), int(bool(precond_fp32)))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
-                                    fused_restriction=bool(fused_restriction), precond_fp32=bool(precond_fp32))
+                                    fused_restriction=bool(fused_restriction), precond_fp32=bool(precond_fp32),
+                                    edge_currents_every_step=bool(edge_currents_every_step))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
         self._refresh_fused_restriction()
 

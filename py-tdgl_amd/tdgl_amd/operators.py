@@ -53,6 +53,7 @@ class MeshOperators:
         amg_smoothing_sweeps: int = 2,
         edge_currents_every_step: bool = True,
         reorder="rcm",
+        precond_fp32: bool = True,
     ):
         self.mesh = mesh
         self.areas = mesh.areas
@@ -65,7 +66,7 @@ class MeshOperators:
         self._opts = dict(
             u=u, gamma=gamma, device_id=device_id, pcg_rtol=pcg_rtol, pcg_max_iter=pcg_max_iter,
             nu=amg_smoothing_sweeps, edge_currents_every_step=edge_currents_every_step,
-            reorder=reorder,
+            reorder=reorder, precond_fp32=precond_fp32,
         )
         self.ctx: Union[TDGLContext, None] = None
         self.hierarchy = None
@@ -85,6 +86,11 @@ class MeshOperators:
             rtol=o["pcg_rtol"], max_iter=o["pcg_max_iter"], nu=o["nu"],
             edge_currents_every_step=o["edge_currents_every_step"],
         )
+        if not o["precond_fp32"]:
+            po = dict(self.ctx.poisson_options)
+            po["smoother"] = "jacobi" if po["smoother"] == 0 else "chebyshev"
+            po["precond_fp32"] = False
+            self.ctx.set_poisson_options(**po)
         n, m = self.ctx.n, self.ctx.m
         ctx = self.ctx
         self.mu_gradient = _DeviceOperator("mu_gradient", (m, n), lambda mu: -ctx.normal_current(mu))

@@ -63,6 +63,7 @@ class SolverOptions:
     pcg_rtol: float = 1e-10
     pcg_max_iter: int = 500
     amg_smoothing_sweeps: int = 2  # Chebyshev degree of the AMG smoother
+    pcg_precond_fp32: bool = True  # store the V-cycle's operators in fp32 (arithmetic and CG stay fp64)
     edge_currents_every_step: bool = True
     device_id: int = 0
 

@@ -294,6 +294,7 @@ class TDGLSolver:
             pcg_max_iter=options.pcg_max_iter,
             amg_smoothing_sweeps=options.amg_smoothing_sweeps,
             edge_currents_every_step=options.edge_currents_every_step,
+            precond_fp32=options.pcg_precond_fp32,
         )
         self.operators.build_operators()
         self.ctx = self.operators.ctx
