@@ -213,7 +213,7 @@ def test_psi_update_matches_reference_including_failures():
 
 
 # ------------------------------------------------------------------ trajectories
-def _hip_solver(g, mesh, b, terminals=(), current_func=None, **opt_override):
+def _hip_solver(g, mesh, b, terminals=(), current_func=None, precond_fp32=True, **opt_override):
     from tdgl_amd import SolverOptions, TDGLSolver
 
     o = options_from_golden(g, **opt_override)
@@ -221,7 +221,7 @@ def _hip_solver(g, mesh, b, terminals=(), current_func=None, **opt_override):
         solve_time=o.solve_time, skip_time=o.skip_time, dt_init=o.dt_init, dt_max=o.dt_max,
         adaptive=o.adaptive, adaptive_window=o.adaptive_window, max_solve_retries=o.max_solve_retries,
         adaptive_time_step_multiplier=o.adaptive_time_step_multiplier, save_every=o.save_every,
-        terminal_psi=o.terminal_psi, pcg_rtol=1e-11,
+        terminal_psi=o.terminal_psi, pcg_rtol=1e-11, pcg_precond_fp32=precond_fp32,
     )
     probes = [int(p) for p in g["probe_points"]] if "probe_points" in g else None
     return TDGLSolver.from_dimensionless(
@@ -276,10 +276,14 @@ def test_trajectory_uniform_field_vortex_entry():
     assert (np.abs(sol.tdgl_data.psi) ** 2).min() < 0.05
 
 
-def test_trajectory_fixed_dt():
+@pytest.mark.parametrize("precond_fp32", [True, False])
+def test_trajectory_fixed_dt(precond_fp32):
+    """(also: the V-cycle's operators stored in fp32 or fp64 -- same trajectory, the CG is fp64)"""
     g = load_golden("traj_field_small_fixed_dt")
     mesh = reference_mesh(load_golden("mesh_small"))
-    sol = _hip_solver(g, mesh, float(g["b"])).solve()
+    solver = _hip_solver(g, mesh, float(g["b"]), precond_fp32=precond_fp32)
+    assert solver.ctx.poisson_options["precond_fp32"] == precond_fp32
+    sol = solver.solve()
     _assert_hip_trajectory(g, sol, 2e-8)  # measured: 9e-10
     assert np.all(sol.dynamics.dt == float(g["opt_dt_init"]))
 
