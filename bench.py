@@ -235,6 +235,7 @@ def main():
 
     # ---- timed region: exactly K steps -----------------------------------------------------
     ctx.profile_enable(True)
+    ctx.comm_stats(reset=True)
     barrier()
     t_begin = time.perf_counter()
     res = ctx.run(args.steps)
@@ -243,6 +244,7 @@ def main():
     assert len(res["dt"]) == args.steps
     launches, k1_ms = ctx.profile_read()
     ctx.profile_enable(False)
+    comm = ctx.comm_stats()
     if dist is not None:
         import torch
 
@@ -310,6 +312,15 @@ def main():
                  vcycle_ms=vc_ms, dt_last=float(res["dt"][-1])),
         kernels=kernels,
     )
+    if use_dd:  # what rank 0 exchanged per step (every rank issues the same sequence)
+        out["comm_per_step"] = dict(
+            halo_exchanges=round(comm["halos"] / args.steps, 1),
+            halo_bytes_sent=int(comm["halo_bytes"] / args.steps),
+            allreduces=round(comm["allreduces"] / args.steps, 1),
+            allreduce_bytes=int(comm["allreduce_bytes"] / args.steps),
+            neighbours=len(drun.lp.neighbors), ghost_sites=int(drun.lp.n_ghost),
+            overlap=bool(ctx.comm_overlap()[0]), interior_rows=int(ctx.comm_overlap()[1]),
+        )
     if start_state is not None:
         log("timing the CPU oracle (LU factorisation first; this takes a while at 1M sites)")
         out["cpu_baseline"] = cpu_baseline(mesh, A, start_state, opt_kw, target_seconds=args.cpu_seconds,

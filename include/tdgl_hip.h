@@ -187,6 +187,9 @@ int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn
  * first (tdgl_amd.partition does); interior_rows reports the prefix the library found. */
 int tdgl_set_comm_overlap(tdgl_ctx *ctx, int32_t on);
 int tdgl_get_comm_overlap(tdgl_ctx *ctx, int32_t *enabled, int64_t *interior_rows);
+/* Communication counters of this rank since creation / the last reset:
+ * out4 = {halo exchanges, bytes sent in them, all-reduces, bytes all-reduced}. */
+int tdgl_get_comm_stats(tdgl_ctx *ctx, int64_t *out4, int32_t reset);
 
 /* ------------------------------------------------------------------ inputs */
 /* MeshOperators.set_link_exponents (operators.py:310-383): A[n_edges, 2], dimensionless.

@@ -139,6 +139,7 @@ SIGNATURES = {
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),
     "tdgl_comm_init_callbacks": (C.c_int, [_CTX, HALO_FN, ALLREDUCE_FN, C.c_void_p]),
     "tdgl_set_comm_overlap": (C.c_int, [_CTX, C.c_int32]),
+    "tdgl_get_comm_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.c_int32]),
     "tdgl_get_comm_overlap": (C.c_int, [_CTX, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "tdgl_set_link_exponents": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_link_exponents_base": (C.c_int, [_CTX, c_f64p, C.c_double]),

@@ -180,6 +180,12 @@ class TDGLContext:
         """Overlap halo exchanges with the ghost-free rows on a second HIP stream (default on)."""
         self._chk(self._lib.tdgl_set_comm_overlap(self._ctx, int(bool(on))))
 
+    def comm_stats(self, reset=False):
+        """``dict(halos, halo_bytes, allreduces, allreduce_bytes)`` of this rank since the last reset."""
+        out = (C.c_int64 * 4)()
+        self._chk(self._lib.tdgl_get_comm_stats(self._ctx, out, int(bool(reset))))
+        return dict(halos=out[0], halo_bytes=out[1], allreduces=out[2], allreduce_bytes=out[3])
+
     def comm_overlap(self):
         on, rows = C.c_int32(0), C.c_int64(0)
         self._chk(self._lib.tdgl_get_comm_overlap(self._ctx, C.byref(on), C.byref(rows)))
