@@ -20,6 +20,9 @@ from types import SimpleNamespace
 
 import numpy as np
 
+# the host driver of this pool only supports dmabuf IPC: RCCL needs this before the runtime loads
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd")):
     if p not in sys.path:

@@ -23,6 +23,8 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL (must precede the runtime)
+
 from .amg import build_hierarchy
 from .hipcore import TDGLContext, poisson_matrix
 from .partition import build_local_problem, rcb_partition
