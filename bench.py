@@ -131,7 +131,13 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the domain-decomposition driver (RCCL communicator) even on one GPU")
+    ap.add_argument("--timeout", type=int, default=1500,
+                    help="hard limit in seconds for the whole run (SIGALRM ends a hung rank instead of blocking the node); 0 = none")
     args = ap.parse_args()
+    if args.timeout > 0:
+        import signal
+
+        signal.alarm(args.timeout)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
