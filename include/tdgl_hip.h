@@ -180,11 +180,14 @@ typedef int (*tdgl_halo_fn)(void *user, const double *send, const int64_t *send_
                             const int64_t *recv_off, int32_t n_neighbors, const int32_t *neighbor_ranks);
 typedef int (*tdgl_allreduce_fn)(void *user, double *buf, int64_t count, int32_t op);
 int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn allreduce, void *user);
-/* Overlap of the halo exchanges with the ghost-free rows (default on): the stencil kernels that
- * follow an exchange (psi Laplacian + rhs; level-0 residual of the V-cycle; A p of the CG) run
- * their leading ghost-free 256-row tiles on the compute stream while the exchange travels on a
- * second HIP stream, and the remaining rows after it.  Needs the owned sites numbered interior
- * first (tdgl_amd.partition does); interior_rows reports the prefix the library found. */
+/* Overlap of the halo exchanges with the ghost-free rows: the stencil kernels that follow an
+ * exchange (psi Laplacian + rhs; level-0 residual of the V-cycle; A p of the CG; edge currents)
+ * run their leading ghost-free part on the compute stream while the exchange travels on a second
+ * HIP stream, and the rest after it.  Needs the owned sites numbered interior first
+ * (tdgl_amd.partition does); interior_rows reports the prefix the library found.
+ * mode: 0 = never, 1 = automatic (default: only when the ghost-free part is large enough to pay
+ * for the two cross-stream dependencies an overlapped exchange costs), 2 = always.
+ * tdgl_get_comm_overlap reports whether exchanges are overlapped with the current plan. */
 int tdgl_set_comm_overlap(tdgl_ctx *ctx, int32_t on);
 int tdgl_get_comm_overlap(tdgl_ctx *ctx, int32_t *enabled, int64_t *interior_rows);
 /* Communication counters of this rank since creation / the last reset:

@@ -151,7 +151,7 @@ struct tdgl_ctx {
     int int_tiles = 0;        // leading 256-row tiles whose rows have no ghost neighbour
     int64_t m_int = 0;        // leading edges (internal order) between two owned sites
     bool defer_mu_halo = false;  // pcg_solve leaves the exchange of mu's ghosts pending (run.inc)
-    bool overlap = true;      // tdgl_set_comm_overlap
+    int overlap = 1;          // tdgl_set_comm_overlap: 0 off, 1 auto (by size), 2 always
     int64_t stat_halos = 0, stat_halo_bytes = 0, stat_allreduces = 0, stat_allreduce_bytes = 0;
     double *pend_v = nullptr; // exchange started by comm_halo_start, completed by comm_halo_wait
     int pend_width = 0;

@@ -50,7 +50,7 @@ def stdout_to_stderr():
 class DistributedTDGL:
     def __init__(self, mesh, options, link_exponents, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
                  terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
-                 overlap=True):
+                 overlap="auto"):
         import torch.distributed as dist
 
         self.dist = dist

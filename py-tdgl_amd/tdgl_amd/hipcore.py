@@ -176,9 +176,12 @@ class TDGLContext:
         self._cb_keep = (_lib.HALO_FN(_halo), _lib.ALLREDUCE_FN(_allreduce))
         self._chk(self._lib.tdgl_comm_init_callbacks(self._ctx, self._cb_keep[0], self._cb_keep[1], None))
 
-    def set_comm_overlap(self, on=True):
-        """Overlap halo exchanges with the ghost-free rows on a second HIP stream (default on)."""
-        self._chk(self._lib.tdgl_set_comm_overlap(self._ctx, int(bool(on))))
+    def set_comm_overlap(self, mode="auto"):
+        """Overlap halo exchanges with the ghost-free rows on a second HIP stream: ``"auto"``
+        (default; only for partitions big enough to pay for the cross-stream dependencies),
+        ``True`` / ``"always"``, ``False`` / ``"never"``."""
+        code = {"auto": 1, "always": 2, "never": 0, True: 2, False: 0}[mode]
+        self._chk(self._lib.tdgl_set_comm_overlap(self._ctx, code))
 
     def comm_stats(self, reset=False):
         """``dict(halos, halo_bytes, allreduces, allreduce_bytes)`` of this rank since the last reset."""
