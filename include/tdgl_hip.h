@@ -320,7 +320,10 @@ int tdgl_vcycle(tdgl_ctx *ctx, const double *r, double *z);
  * stream, timed with HIP events.  kernel: 0 = psi-Laplacian SpMV (K1), 1 = fused
  * psi-Laplacian + rhs, 2 = pointwise psi update, 3 = edge currents, 4 = level-0 Poisson
  * SpMV, 5 = level-0 V-cycle, 6 = copy (device memcpy ceiling, bytes = 16 * n_sites r+w),
- * 7 = induced vector potential (screening; n_edges * n_sites pairs, ~12 fp64 flops each). */
+ * 7 = induced vector potential (screening; n_edges * n_sites pairs, ~12 fp64 flops each),
+ * 8 / 9 = two trivial dependent kernels across two streams (event record + wait each way) / in one
+ * stream: their difference is the price of the two cross-stream dependencies an overlapped halo
+ * exchange pays. */
 int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms);
 /* Enable/disable HIP-event timing of the fused psi-Laplacian kernel inside tdgl_run, and
  * read back the accumulated launches / milliseconds. */

@@ -865,6 +865,18 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
                 if (!ctx->scr_enabled) return TDGL_ERR_ARG;
                 launch_induced(ctx);
                 break;
+            case 8:  // two trivial kernels, the second on the communication stream and back
+                hipLaunchKernelGGL(k_copy_d2, dim3(1), dim3(BLOCK), 0, ctx->stream, 64, psi, tmp_c.p);
+                (void)hipEventRecord(ctx->ev_pack, ctx->stream);
+                (void)hipStreamWaitEvent(ctx->comm_stream, ctx->ev_pack, 0);
+                hipLaunchKernelGGL(k_copy_d2, dim3(1), dim3(BLOCK), 0, ctx->comm_stream, 64, psi, tmp_c.p + 64);
+                (void)hipEventRecord(ctx->ev_halo, ctx->comm_stream);
+                (void)hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0);
+                break;
+            case 9:  // the same two kernels in one stream
+                hipLaunchKernelGGL(k_copy_d2, dim3(1), dim3(BLOCK), 0, ctx->stream, 64, psi, tmp_c.p);
+                hipLaunchKernelGGL(k_copy_d2, dim3(1), dim3(BLOCK), 0, ctx->stream, 64, psi, tmp_c.p + 64);
+                break;
             default: return TDGL_ERR_ARG;
         }
         return TDGL_OK;
