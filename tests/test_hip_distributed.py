@@ -131,6 +131,22 @@ def test_halo_overlap_on_second_stream_matches_single_gpu(overlap, tmp_path):
     assert np.abs(got["normal_current"] - ref["normal_current"]).max() < 1e-9
 
 
+def test_eight_ranks_match_single_gpu(tmp_path):
+    """The node size of the scaling runs: 8 ranks (here sharing one GPU through the callback
+    transport), 2x4 RCB blocks with up to 5 neighbours per rank, corner-only contacts included."""
+    size = (120, 60)
+    mesh, ref_res, ref = _single_gpu_reference(size)
+    mp.spawn(_worker, args=(8, _free_port(), "gloo", str(tmp_path), "auto", size), nprocs=8, join=True)
+    got = np.load(os.path.join(tmp_path, "dist_gloo_8.npz"))
+    assert len(got["dt"]) == N_STEPS
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-9
+    assert np.abs(got["mu"] - ref["mu"]).max() < 1e-9 * max(1.0, np.abs(ref["mu"]).max())
+    assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-9
+    assert np.abs(got["normal_current"] - ref["normal_current"]).max() < 1e-9
+    assert not bool(got["overlap"])  # automatic mode: partitions this small do not overlap
+
+
 def test_rccl_transport_world_size_one(tmp_path):
     mesh, ref_res, ref = _single_gpu_reference()
     mp.spawn(_worker, args=(1, _free_port(), "rccl", str(tmp_path)), nprocs=1, join=True)
