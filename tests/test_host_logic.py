@@ -228,6 +228,30 @@ def test_make_mesh_with_smoothing_keeps_boundary_and_topology():
     assert b.edge_mesh.dual_edge_lengths.min() >= 0 and b.areas.min() > 0
 
 
+def test_parameter_arithmetic_and_separable_products():
+    """`Parameter` algebra (tdgl/parameter.py) and the recognition of A(t) = f(t) * A_static."""
+    from tdgl_amd.parameter import ConstantField, LinearRamp, Parameter
+
+    x, y, z = np.linspace(-1, 1, 5), np.linspace(0, 2, 5), np.zeros(5)
+    field = ConstantField(2.0)
+    ramp = LinearRamp(tmin=1.0, tmax=3.0, initial=0.5, final=1.5)
+    assert not field.time_dependent and ramp.time_dependent and ramp.uniform_in_space
+    assert ramp.scalar(0.0) == 0.5 and ramp.scalar(2.0) == 1.0 and ramp.scalar(9.0) == 1.5
+    for prod in (ramp * field, field * ramp):
+        assert prod.time_dependent
+        f, static = prod.separable_product()
+        assert f is ramp and static is field
+        assert np.allclose(prod(x, y, z, t=2.0), 1.0 * field(x, y, z))
+        assert np.allclose(prod(x, y, z, t=0.0), 0.5 * field(x, y, z))
+    assert (field + ramp * field).separable_product() is None       # not a pure product
+    assert (field * 2.0).separable_product() is None                # nothing time dependent
+    moving = Parameter(lambda x, y, z, *, t: np.stack([x * t, y, z], axis=1))
+    assert (ramp * moving).separable_product() is None              # the field itself moves
+    assert np.allclose((2.0 * field - field)(x, y, z), field(x, y, z))
+    with pytest.raises(ValueError, match="'t' cannot be bound"):
+        Parameter(lambda x, y, z, *, t: x, t=1.0)
+
+
 # ---------------------------------------------------------------- HDF5 layout (no h5py needed)
 class _FakeGroup(dict):
     """Minimal stand-in for an h5py group: nested dict + attrs."""
