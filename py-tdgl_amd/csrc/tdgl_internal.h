@@ -111,7 +111,10 @@ struct AmgLevel {
 };
 
 // scalars of the PCG recurrence, resident on the device
-enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_COUNT = 4 };
+// (S_CONV_IT: first frozen iteration or -1; S_IT: iterations launched so far in this solve; S_TOL2:
+// rtol^2 ||b||^2 -- kept on the device so that the iteration kernels take no per-iteration
+// arguments and a pair of iterations can be replayed as a hipGraph)
+enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_COUNT = 8 };
 
 // what a step reports back to the host at its synchronisation point
 struct StepStatus {
@@ -205,6 +208,12 @@ struct tdgl_ctx {
     tdgl::DevBuf<float> fusedR32;         // its values in fp32
     bool f32_ready = false;               // fp32 copies are current
     bool coarse32_ready = false;          // ... of the intermediate-level operators
+    // two consecutive PCG iterations (odd, even) captured as a hipGraph: replayed while the
+    // solve is launch bound (small meshes); re-captured when anything it bakes in changes
+    hipGraphExec_t pcg_graph = nullptr;
+    int64_t pcg_graph_epoch = -1, pcg_epoch = 0;
+    int pcg_graph_mode = -1;              // (f32 | coarse32 << 1) it was captured with
+    bool use_graph = true;
     int64_t f32_fallbacks = 0;            // solves that had to be finished with the fp64 operators
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
