@@ -143,6 +143,7 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_pack) (void)hipEventDestroy(ctx->ev_pack);
     if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
+    if (ctx->pcg_graph) (void)hipGraphExecDestroy(ctx->pcg_graph);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     for (auto &pr : ctx->prof_pending) {
         (void)hipEventDestroy(pr.first);
