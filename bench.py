@@ -46,6 +46,7 @@ B_FIELD = 0.1  # B / Bc2
 # ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction calibrated on a copy kernel in the same
 # run: profiles/r01h_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
 PMC_TRAFFIC_BYTES = {"1M": 175.7e6}
+PMC_TRAFFIC_AXP_BYTES = {"1M": 98.0e6}
 
 
 def log(*a):
@@ -252,6 +253,7 @@ def main():
     elapsed = time.perf_counter() - t_begin
     assert len(res["dt"]) == args.steps
     launches, k1_ms = ctx.profile_read()
+    axp_launches, axp_ms = ctx.profile_read_pcg() if not use_dd else (0, 0.0)
     ctx.profile_enable(False)
     comm = ctx.comm_stats()
     if dist is not None:
@@ -284,6 +286,22 @@ def main():
         avg_launch_ms=round(k1_avg_ms, 5),
         launches=launches,
     )
+    # the kernel that dominates the run time: the CG's fused direction update + A p (k_sell_axp), timed
+    # in the run on the first 256 launches; algorithmic bytes = K5 SpMV + the direction update's 24 n
+    roofline_pcg = None
+    if axp_launches > 0:
+        axp_alg = ab["K5_pcg_spmv"] + 24 * n_loc
+        axp_avg_ms = axp_ms / axp_launches
+        roofline_pcg = dict(
+            bound="hbm",
+            kernel="k_sell_axp (CG direction update p = z + beta p fused with q = A p and the p.q partials; "
+                   "one launch per PCG iteration, the largest single share of the run time)",
+            achieved=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            traffic=PMC_TRAFFIC_AXP_BYTES.get(args.workload),
+            traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01h_pmc_hbm_traffic_1M.txt",
+            algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=axp_launches,
+        )
     # stand-alone kernel timings (same buffers, back-to-back launches) for the other rows
     names = {0: "K1_psi_laplacian_spmv", 2: "K2_psi_update", 3: "K3_supercurrent", 4: "K5_pcg_spmv", 6: "copy_c128"}
     kernels = {}
@@ -317,6 +335,7 @@ def main():
             f"domain decomposition (RCB, {world} ranks, ~{n // world} sites each), RCCL halo exchange + all-reduce",
         ),
         roofline=roofline,
+        roofline_pcg=roofline_pcg,
         pcg=dict(mean_iterations=round(float(res["pcg_iters"].mean()), 2), max_iterations=int(res["pcg_iters"].max()),
                  vcycle_ms=vc_ms, dt_last=float(res["dt"][-1])),
         kernels=kernels,

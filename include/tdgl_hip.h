@@ -329,6 +329,9 @@ int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms
  * read back the accumulated launches / milliseconds. */
 int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on);
 int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
+/* The same for the kernel that dominates the run time, the CG's fused direction update + A p
+ * (k_sell_axp): the first 256 launches after tdgl_profile_enable are timed (single GPU). */
+int tdgl_profile_read_pcg(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus
 }

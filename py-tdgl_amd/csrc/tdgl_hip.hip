@@ -149,6 +149,10 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (auto &pr : ctx->prof2_pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     hipStream_t s = ctx->stream;
     delete ctx;  // frees the DevBufs
     if (s) (void)hipStreamDestroy(s);
@@ -812,6 +816,9 @@ extern "C" int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on) {
     ctx->profile = on != 0;
     ctx->prof_launches = 0;
     ctx->prof_ms = 0.0;
+    ctx->prof2_launches = 0;
+    ctx->prof2_ms = 0.0;
+    ctx->prof2_budget = on ? 256 : 0;
     return TDGL_OK;
 }
 
@@ -826,6 +833,24 @@ static int profile_drain(tdgl_ctx *ctx) {
         (void)hipEventDestroy(pr.second);
     }
     ctx->prof_pending.clear();
+    for (auto &pr : ctx->prof2_pending) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->prof2_ms += ms;
+        ctx->prof2_launches += 1;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ctx->prof2_pending.clear();
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_profile_read_pcg(tdgl_ctx *ctx, int64_t *launches, double *total_ms) {
+    CTX_GUARD(ctx);
+    TDGL_TRY(profile_drain(ctx));
+    if (launches) *launches = ctx->prof2_launches;
+    if (total_ms) *total_ms = ctx->prof2_ms;
     return TDGL_OK;
 }
 

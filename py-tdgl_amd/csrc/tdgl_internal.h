@@ -267,4 +267,9 @@ struct tdgl_ctx {
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+    // the same for the kernel that dominates the run time (the CG's fused A p), sampled: only the
+    // first prof2_budget launches after tdgl_profile_enable are bracketed by events
+    int64_t prof2_launches = 0, prof2_budget = 0;
+    double prof2_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_pending;
 };

@@ -488,6 +488,11 @@ class TDGLContext:
     def profile_enable(self, on=True):
         self._chk(self._lib.tdgl_profile_enable(self._ctx, int(bool(on))))
 
+    def profile_read_pcg(self):
+        n, ms = C.c_int64(0), C.c_double(0)
+        self._chk(self._lib.tdgl_profile_read_pcg(self._ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def profile_read(self):
         n, ms = C.c_int64(0), C.c_double(0)
         self._chk(self._lib.tdgl_profile_read(self._ctx, C.byref(n), C.byref(ms)))
