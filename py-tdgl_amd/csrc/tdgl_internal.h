@@ -114,7 +114,8 @@ struct AmgLevel {
 // (S_CONV_IT: first frozen iteration or -1; S_IT: iterations launched so far in this solve; S_TOL2:
 // rtol^2 ||b||^2 -- kept on the device so that the iteration kernels take no per-iteration
 // arguments and a pair of iterations can be replayed as a hipGraph)
-enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_COUNT = 8 };
+// (S_CG_*: r.z and alpha of the previous iteration for the single-reduction CG, ping-pong by parity)
+enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_CG_RZ0, S_CG_RZ1, S_CG_ALPHA0, S_CG_ALPHA1, S_COUNT = 12 };
 
 // what a step reports back to the host at its synchronisation point
 struct StepStatus {
