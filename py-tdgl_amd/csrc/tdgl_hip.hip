@@ -35,15 +35,6 @@ using namespace tdgl;
 
 static inline int grid_for(int64_t n, int block = BLOCK) { return (int)((n + block - 1) / block); }
 
-// number of workgroups for a SELL kernel: 4 slices per group, rounded up to a multiple of
-// the XCD count so that xcd_tile() is a bijection onto [0, per_xcd * 8)
-static inline void sell_grid(int n_slices, int *per_xcd, int *grid) {
-    const int tiles = (n_slices + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-    *per_xcd = (tiles + XCDS - 1) / XCDS;
-    if (*per_xcd < 1) *per_xcd = 1;
-    *grid = *per_xcd * XCDS;
-}
-
 // ---------------------------------------------------------------------------------------
 // SELL construction from CSR (host)
 static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
