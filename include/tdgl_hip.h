@@ -237,8 +237,7 @@ int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_probe);
  * is iterated to self-consistency with Polyak's heavy-ball update; the link variables use
  * A_applied + A_induced.  sites_xy [n,2] / edge_centers_xy [m,2] are the dimensionful positions
  * and site_areas [n] the areas already multiplied by the screening scale, exactly the arrays the
- * reference passes to its kernel (solver.py:307-313).  opts == NULL switches screening off.
- * Not available in one-process-per-GPU mode. */
+ * reference passes to its kernel (solver.py:307-313).  opts == NULL switches screening off. */
 typedef struct {
     int32_t max_iterations;   /* SolverOptions.max_iterations_per_step */
     double tolerance;         /* SolverOptions.screening_tolerance      */
@@ -247,6 +246,13 @@ typedef struct {
 } tdgl_screening_options;
 int tdgl_set_screening(tdgl_ctx *ctx, const tdgl_screening_options *opts, const double *sites_xy,
                        const double *edge_centers_xy, const double *site_areas);
+/* The same in one-process-per-GPU mode (after tdgl_set_halo_plan): the 1/r sum runs over ALL sites,
+ * so every rank passes the GLOBAL site coordinates / scaled areas (global order) and the global
+ * ids of its owned sites, plus the centres of its local edges.  Per screening iteration the owned
+ * site currents are scattered into a global array that is summed over ranks (all-reduce). */
+int tdgl_set_screening_distributed(tdgl_ctx *ctx, const tdgl_screening_options *opts, const double *global_sites_xy,
+                                   const double *global_site_areas, const int64_t *owned_global_ids,
+                                   const double *edge_centers_xy);
 /* A_induced [n_edges, 2] in reference edge order (seed / read-out; solver.py:738, 751). */
 int tdgl_set_induced_vector_potential(tdgl_ctx *ctx, const double *A_induced);
 int tdgl_get_induced_vector_potential(tdgl_ctx *ctx, double *A_induced);

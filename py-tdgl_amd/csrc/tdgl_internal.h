@@ -260,6 +260,11 @@ struct tdgl_ctx {
     int scr_chunks = 1, scr_tiles_per_chunk = 1;
     tdgl::DevBuf<double> abs_sq_old;     // |psi^n|^2 of the step's starting psi [n_pad]
     tdgl::DevBuf<unsigned long long> scr_err_bits;
+    // one-process-per-GPU mode: the 1/r sum runs over ALL sites; every rank scatters the site
+    // currents of its owned sites into a global array that is summed over ranks
+    int64_t scr_n_sites = 0;             // sites the kernel sums over (n, or n_global)
+    tdgl::DevBuf<int64_t> scr_owned_gid; // global id of each owned site
+    tdgl::DevBuf<double> scr_Jglobal;    // [2 * n_global_pad]
     int32_t last_screening_iters = 0;
 
     // ---- measurement -------------------------------------------------------------------

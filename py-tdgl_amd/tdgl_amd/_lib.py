@@ -161,6 +161,9 @@ SIGNATURES = {
     "tdgl_set_screening": (
         C.c_int, [_CTX, C.POINTER(ScreeningOptions), c_f64p, c_f64p, c_f64p]
     ),
+    "tdgl_set_screening_distributed": (
+        C.c_int, [_CTX, C.POINTER(ScreeningOptions), c_f64p, c_f64p, C.POINTER(C.c_int64), c_f64p]
+    ),
     "tdgl_set_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
     "tdgl_get_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
     "tdgl_induced_vector_potential": (C.c_int, [_CTX, c_f64p, c_f64p]),

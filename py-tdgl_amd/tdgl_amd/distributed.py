@@ -50,7 +50,7 @@ def stdout_to_stderr():
 class DistributedTDGL:
     def __init__(self, mesh, options, link_exponents, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
                  terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
-                 overlap="auto"):
+                 overlap="auto", screening=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -87,7 +87,8 @@ class DistributedTDGL:
                 raise ValueError(f"unknown transport {transport!r}")
         # the same global hierarchy on every rank (deterministic set-up), level 0 sliced
         A_glob = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
-        self.hierarchy = build_hierarchy(A_glob)
+        # (level 0 is the distributed one, so the hierarchy needs at least one coarser level)
+        self.hierarchy = build_hierarchy(A_glob, max_coarse=min(600, max(8, n // 4)))
         ctx.set_hierarchy_distributed(self.hierarchy, lp)
         ctx.set_poisson_options(
             rtol=options.pcg_rtol, max_iter=options.pcg_max_iter, nu=options.amg_smoothing_sweeps,
@@ -99,6 +100,15 @@ class DistributedTDGL:
         self.set_mu_boundary(np.zeros(len(em.boundary_edge_indices)) if mu_boundary is None else mu_boundary)
         ctx.set_controller(options.dt_init, options.dt_max, options.adaptive, options.adaptive_window,
                            options.max_solve_retries, options.adaptive_time_step_multiplier)
+        # screening: ``dict(sites[n, 2], areas[n] (scaled), edge_centers[m, 2])`` in GLOBAL numbering
+        self.screening = screening
+        if screening is not None:
+            ctx.set_screening_distributed(
+                screening["sites"], screening["areas"], l2g[: lp.n_own],
+                np.asarray(screening["edge_centers"])[lp.edge_local_to_global],
+                max_iterations=options.max_iterations_per_step, tolerance=options.screening_tolerance,
+                step_size=options.screening_step_size, step_drag=options.screening_step_drag,
+            )
         # probes: each rank reads the ones it owns
         self.probe_points = None if probe_points is None else np.asarray(probe_points, dtype=np.int64)
         if self.probe_points is not None:
@@ -169,15 +179,21 @@ class DistributedTDGL:
         own = lp.local_to_global[: lp.n_own]
         sites = np.zeros((3, n))
         sites[0, own], sites[1, own], sites[2, own] = st["psi"].real[: lp.n_own], st["psi"].imag[: lp.n_own], st["mu"][: lp.n_own]
-        edges = np.zeros((2, m))
+        edges = np.zeros((4, m))
         mask = lp.owned_edge_mask
         ge = lp.edge_local_to_global[mask]
         edges[0, ge], edges[1, ge] = st["supercurrent"][mask], st["normal_current"][mask]
+        if self.screening is not None:
+            a_ind = self.ctx.induced_vector_potential()
+            edges[2, ge], edges[3, ge] = a_ind[mask, 0], a_ind[mask, 1]
         if self.world > 1:
             for arr in (sites, edges):
                 t = torch.from_numpy(arr)
                 self.dist.all_reduce(t)
-        return dict(psi=sites[0] + 1j * sites[1], mu=sites[2], supercurrent=edges[0], normal_current=edges[1])
+        out = dict(psi=sites[0] + 1j * sites[1], mu=sites[2], supercurrent=edges[0], normal_current=edges[1])
+        if self.screening is not None:
+            out["induced_vector_potential"] = np.column_stack([edges[2], edges[3]])
+        return out
 
     def close(self):
         self.ctx.close()

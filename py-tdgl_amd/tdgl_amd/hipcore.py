@@ -387,6 +387,18 @@ class TDGLContext:
             raise ValueError("set_screening: sites (n, 2), edge_centers (m, 2), areas (n,) expected")
         self._chk(self._lib.tdgl_set_screening(self._ctx, C.byref(opts), p_f64(sites), p_f64(edge_centers), p_f64(areas)))
 
+    def set_screening_distributed(self, global_sites, global_areas, owned_global_ids, edge_centers,
+                                  max_iterations=1000, tolerance=1e-3, step_size=0.1, step_drag=0.5):
+        """Screening in one-process-per-GPU mode: global site arrays (global order), the global ids
+        of this rank's owned sites and the centres of its local edges."""
+        opts = _lib.ScreeningOptions(int(max_iterations), float(tolerance), float(step_size), float(step_drag))
+        gs, ga, ec = f64(global_sites), f64(global_areas), f64(edge_centers)
+        ids = np.ascontiguousarray(owned_global_ids, dtype=np.int64)
+        if gs.ndim != 2 or gs.shape[1] != 2 or ga.shape != (len(gs),) or ec.shape != (self.m, 2) or len(ids) != self.n_owned:
+            raise ValueError("set_screening_distributed: inconsistent array shapes")
+        self._chk(self._lib.tdgl_set_screening_distributed(
+            self._ctx, C.byref(opts), p_f64(gs), p_f64(ga), ids.ctypes.data_as(C.POINTER(C.c_int64)), p_f64(ec)))
+
     def set_induced_vector_potential(self, A):
         A = f64(A)
         if A.shape != (self.m, 2):

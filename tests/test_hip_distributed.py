@@ -147,6 +147,65 @@ def test_eight_ranks_match_single_gpu(tmp_path):
     assert not bool(got["overlap"])  # automatic mode: partitions this small do not overlap
 
 
+def _screening_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from conftest import load_golden
+    from helpers import options_from_golden, reference_mesh, uniform_field_A
+    from tdgl_amd import SolverOptions, _lib
+
+    _lib.load()
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdgl_amd.distributed import DistributedTDGL
+
+        g = load_golden("traj_screening_tiny")
+        mesh = reference_mesh(g)
+        o = options_from_golden(g)
+        opts = SolverOptions(
+            solve_time=o.solve_time, dt_init=o.dt_init, dt_max=o.dt_max, save_every=o.save_every, pcg_rtol=1e-12,
+            include_screening=True, screening_tolerance=float(g["opt_screening_tolerance"]),
+            max_iterations_per_step=int(g["opt_max_iterations_per_step"]),
+            screening_step_size=float(g["opt_screening_step_size"]), screening_step_drag=float(g["opt_screening_step_drag"]),
+        )
+        run = DistributedTDGL(
+            mesh, opts, uniform_field_A(mesh, float(g["b"])), 1.0, rank=rank, world=world, transport="gloo", device_id=0,
+            screening=dict(sites=mesh.sites, edge_centers=mesh.edge_mesh.centers,
+                           areas=float(g["screening_scale"]) * mesh.areas),
+        )
+        run.set_state(np.ones(len(mesh.sites), dtype=complex), np.zeros(len(mesh.sites)))
+        run.begin_stage()
+        res = run.run(len(g["call_dt"]))
+        fields = run.gather_state()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"scr_{world}.npz"), dt=res["dt"], iters=res["screening_iterations"], **fields)
+        run.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_screening_on_several_ranks_matches_the_reference_fixture(world, tmp_path):
+    """include_screening in one-process-per-GPU mode: the site currents of all ranks are summed
+    into a global array per screening iteration; against the REFERENCE's trajectory (fixture
+    traj_screening_tiny): same screening iteration counts, same fields, same A_induced."""
+    from conftest import load_golden
+
+    g = load_golden("traj_screening_tiny")
+    mp.spawn(_screening_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"scr_{world}.npz"))
+    assert np.array_equal(got["iters"], g["call_screening_iterations"])
+    assert np.abs(got["dt"] - g["call_dt"]).max() <= 1e-9 * g["call_dt"].max()
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(g["final_psi"]) ** 2).max() < 1e-7
+    assert np.abs(got["supercurrent"] - g["final_supercurrent"]).max() < 1e-7
+    assert np.abs(got["normal_current"] - g["final_normal_current"]).max() < 1e-7
+    assert np.abs(got["induced_vector_potential"] - g["final_A_induced"]).max() < 1e-9
+
+
 def test_rccl_transport_world_size_one(tmp_path):
     mesh, ref_res, ref = _single_gpu_reference()
     mp.spawn(_worker, args=(1, _free_port(), "rccl", str(tmp_path)), nprocs=1, join=True)
