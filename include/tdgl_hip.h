@@ -113,7 +113,8 @@ typedef struct {
                              is an fp32 vector; arithmetic is fp64 and the CG itself (A p,
                              residual recurrence, dot products, convergence test) uses fp64
                              data only, so the solution meets the same rtol.  Active with
-                             nu_fine = 1 and a fused restriction on one GPU.  */
+                             nu_fine = 1 and a fused restriction (z is kept in fp64 in
+                             one-process-per-GPU mode, where its ghosts are exchanged).  */
 } tdgl_poisson_options;
 
 /* ------------------------------------------------------------------ lifetime */
@@ -138,7 +139,8 @@ int tdgl_set_poisson_options(tdgl_ctx *ctx, const tdgl_poisson_options *opts);
  * level-0 smoothing coefficient in use (degree-1 smoothing).  Restricting the pre-smoothed
  * residual then is one product with M instead of a pass over A_0 plus the restriction.  Pure
  * algebraic re-association: the V-cycle is the same operator.  indptr == NULL switches it off;
- * replaced hierarchies drop it.  Ignored in one-process-per-GPU mode. */
+ * replaced hierarchies drop it.  One-process-per-GPU mode: built from the rank's slice (columns =
+ * owned + ghost sites); the partial coarse right-hand sides are summed over ranks. */
 int tdgl_poisson_set_fused_restriction(tdgl_ctx *ctx, int64_t n_rows, int64_t n_cols, const int32_t *indptr,
                                        const int32_t *indices, const double *data, double c);
 /* Optional, for a level 1 <= level < n_levels - 1: R A [n_coarse x n] and A P [n x n_coarse] as CSR,

@@ -233,9 +233,18 @@ def fused_restriction(h: Hierarchy, c: float) -> sp.csr_matrix:
     """``R_0 (I - c A_0 D_0^-1)``: restriction of the residual left by ONE smoothing step
     ``x = c D^-1 b`` from a zero guess, as a single operator on ``b``."""
     lv = h.levels[0]
-    A, R = lv.A.tocsr(), lv.R.tocsr()
-    M = R - (R @ A) @ sp.diags(c * lv.dinv)
-    M = M.tocsr()
+    return fused_restriction_from(lv.A, lv.R, lv.dinv, c)
+
+
+def fused_restriction_from(A, R, dinv, c: float) -> sp.csr_matrix:
+    """The same from explicit pieces.  ``A`` may be a rank's slice [n_own x n_loc] (owned rows,
+    owned + ghost columns) with ``R`` [n_c x n_own] the restriction to its owned fine columns and
+    ``dinv`` over all local sites: the result [n_c x n_loc] then gives this rank's PARTIAL coarse
+    right-hand side, gathering the residual at ghost columns too."""
+    A, R = sp.csr_matrix(A), sp.csr_matrix(R)
+    n_own, n_loc = A.shape
+    Rp = sp.hstack([R, sp.csr_matrix((R.shape[0], n_loc - n_own))]).tocsr() if n_loc > n_own else R
+    M = (Rp - (R @ A) @ sp.diags(c * np.asarray(dinv))).tocsr()
     M.sort_indices()
     return M
 

@@ -203,6 +203,7 @@ class TDGLContext:
         loc = local_hierarchy_level0(h, lp)
         lv0 = Level(A=loc["A"], dinv=loc["dinv"], rho=loc["rho"], P=loc["P"], R=loc["R"])
         hh = Hierarchy(levels=[lv0] + list(h.levels[1:]), coarse_pinv=h.coarse_pinv)
+        self._local_level0 = lv0
         self.set_hierarchy(hh, n_cols0=lp.n_loc)
         self.hierarchy = h
 
@@ -255,16 +256,22 @@ class TDGLContext:
         """(Re)build R0 (I - c A0 D0^-1) for the level-0 smoothing coefficient in use
         (single-GPU, degree-1 smoothing on level 0; `tdgl_poisson_set_fused_restriction`)."""
         h, o = getattr(self, "hierarchy", None), getattr(self, "poisson_options", None)
-        if h is None or o is None or self.n_owned != self.n or len(h.levels) < 2:
+        if h is None or o is None or len(h.levels) < 2:
             return
         if o["nu_fine"] != 1 or not o.get("fused_restriction", True):
             self._chk(self._lib.tdgl_poisson_set_fused_restriction(self._ctx, 0, 0, None, None, None, 0.0))
             return
-        from .amg import fused_restriction, smoother_coefficients
+        from .amg import fused_restriction, fused_restriction_from, smoother_coefficients
 
         name = "jacobi" if o["smoother"] == 0 else "chebyshev"
         c = smoother_coefficients(h.levels[0].rho, 1, name, o["cheb_lo"])[1][0]
-        M = fused_restriction(h, c)
+        lv0 = getattr(self, "_local_level0", None)
+        if lv0 is not None:  # one process per GPU: this rank's slice in LOCAL numbering, ghost columns included
+            M = fused_restriction_from(lv0.A, lv0.R, lv0.dinv, c)
+        elif self.n_owned != self.n:
+            return
+        else:
+            M = fused_restriction(h, c)
         ip, ix, dx = i32(M.indptr), i32(M.indices), f64(M.data)
         self._chk(self._lib.tdgl_poisson_set_fused_restriction(
             self._ctx, M.shape[0], M.shape[1], p_i32(ip), p_i32(ix), p_f64(dx), float(c)))
