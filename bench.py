@@ -328,7 +328,7 @@ def main():
         config=dict(
             workload=f"{desc}, " + ("" if strip else f"uniform field b=B/Bc2={B_FIELD}, ") + f"adaptive dt (dt_init 1e-4, dt_max 0.1), "
                      f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
-                     + ("" if (args.precond_fp64 or use_dd) else "; V-cycle operators stored in fp32, all arithmetic and the CG in fp64")
+                     + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32, all arithmetic and the CG in fp64")
                      + "), J_s/J_n formed every step",
             sites=n, edges=m, amg_levels=h.sizes,
             parallelism="single" if world == 1 else
