@@ -337,7 +337,7 @@ def main():
         roofline=roofline,
         roofline_pcg=roofline_pcg,
         pcg=dict(mean_iterations=round(float(res["pcg_iters"].mean()), 2), max_iterations=int(res["pcg_iters"].max()),
-                 vcycle_ms=vc_ms, dt_last=float(res["dt"][-1])),
+                 vcycle_ms=vc_ms, dt_last=float(res["dt"][-1]), **ctx.poisson_stats()),
         kernels=kernels,
     )
     if use_dd:  # what rank 0 exchanged per step (every rank issues the same sequence)

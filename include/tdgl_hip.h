@@ -151,6 +151,9 @@ int tdgl_poisson_set_fused_restriction(tdgl_ctx *ctx, int64_t n_rows, int64_t n_
 int tdgl_poisson_set_fused_level(tdgl_ctx *ctx, int32_t level, const int32_t *ra_indptr, const int32_t *ra_indices,
                                  const double *ra_data, const int32_t *ap_indptr, const int32_t *ap_indices,
                                  const double *ap_data, const double *p_on_ap_data);
+/* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
+ * solve, 1 if a captured iteration-pair graph is in use}. */
+int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);
 
 /* ------------------------------------------------------------------ one process per GPU
  * The reference is single-process.  Here the mesh is cut into `world` pieces (host layer:

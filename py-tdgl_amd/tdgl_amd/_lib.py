@@ -128,6 +128,7 @@ SIGNATURES = {
     "tdgl_synchronize": (C.c_int, [_CTX]),
     "tdgl_poisson_set_hierarchy": (C.c_int, [_CTX, C.POINTER(AmgLevel), C.c_int32, c_f64p]),
     "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
+    "tdgl_get_poisson_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     "tdgl_poisson_set_fused_level": (
         C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p]
     ),

@@ -485,6 +485,11 @@ class TDGLContext:
         self._chk(self._lib.tdgl_poisson_rhs(self._ctx, p_f64(psi), p_f64(out)))
         return out
 
+    def poisson_stats(self):
+        out = (C.c_int64 * 3)()
+        self._chk(self._lib.tdgl_get_poisson_stats(self._ctx, out))
+        return dict(fp64_fallbacks=out[0], last_iterations=out[1], graph=bool(out[2]))
+
     def poisson_solve(self, rhs, mu0=None):
         rhs = f64(rhs)
         mu = np.zeros(self.n) if mu0 is None else f64(mu0).copy()
