@@ -112,3 +112,33 @@ def test_config3_1m_sites_linearity_and_idempotence_of_operators():
     assert max_abs(ctx.supercurrent(np.ones(n) * np.exp(0.3j)), 0 * mesh.edge_mesh.edge_lengths) < 1e-14
     assert max_abs(ctx.apply_psi_laplacian(np.ones(n) * np.exp(0.3j)), np.zeros(n)) < 1e-12
     ctx.close()
+
+
+@pytest.mark.parametrize("side,n_sites,steps", [(930, 1000431, 30), (1860, 3998502, 8)])
+def test_config3_and_5_steps_satisfy_their_defining_equations(side, n_sites, steps):
+    """BASELINE configs 3 (1M sites, the headline) and 5 (4M sites): the oracle's LU cannot be run at
+    these sizes inside a test, so the stepped state is checked through the equations that define
+    it, with the oracle's operator matrices: L mu = div J_s (solver.py:507-516), J_n = -grad mu
+    (solver.py:519), div (J_s + J_n) = 0, |psi| <= 1, zero-mean mu, bounded PCG work."""
+    from oracle.fv_operators import divergence_matrix, gradient_matrix, laplacian_matrix
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    mesh = synthetic_mesh(side)
+    assert len(mesh.sites) == n_sites
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, dt_max=1e-1, save_every=10**9, pcg_rtol=1e-11)
+    solver = TDGLSolver.from_dimensionless(mesh, opts, uniform_field_A(mesh, 0.1), 1.0, U_DEFAULT, GAMMA_DEFAULT)
+    ctx = solver.ctx
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    res = ctx.run(steps)
+    got = ctx.get_state()
+    assert len(res["dt"]) == steps and res["pcg_iters"].max() <= 45 and ctx.poisson_stats()["fp64_fallbacks"] == 0
+    assert np.all(np.isfinite(got["psi"])) and np.abs(got["psi"]).max() <= 1.0 + 1e-12
+    div = divergence_matrix(mesh)
+    rhs = div @ got["supercurrent"]
+    lap, _ = laplacian_matrix(mesh)
+    scale = max(1.0, np.abs(rhs).max())
+    assert max_abs(lap @ got["mu"], rhs) < 1e-8 * scale  # rtol 1e-11 on the area-weighted system
+    assert max_abs(got["normal_current"], -(gradient_matrix(mesh) @ got["mu"])) < 1e-11 * max(1.0, np.abs(got["mu"]).max())
+    assert max_abs(div @ (got["supercurrent"] + got["normal_current"]), 0 * rhs) < 1e-8 * scale
+    assert abs(got["mu"].mean()) < 1e-11 * max(1.0, np.abs(got["mu"]).max())
