@@ -104,10 +104,15 @@ class Solution:
         """Total sheet current density K = K_s + K_n (`tdgl/solution/solution.py:230-237`)."""
         return self.supercurrent_density + self.normal_current_density
 
-    def current_through_cut(self, x0: float) -> float:
-        """Total dimensionless sheet current crossing the vertical line x = x0 (in units of
-        xi), summed over the mesh edges that cross it: ``sum_e (J_s + J_n)_e s_e sign`` with
-        ``s_e`` the Voronoi dual length.  Discretely conserved."""
+    def current_through_cut(self, x0: float, physical: bool = False) -> float:
+        """Total sheet current crossing the vertical line x = x0, summed over the mesh edges that
+        cross it: ``sum_e (J_s + J_n)_e s_e sign`` with ``s_e`` the Voronoi dual length.  Discretely
+        conserved.  By default dimensionless with ``x0`` in units of
+        xi; ``physical=True``: ``x0`` in ``length_units``, result in ``options.current_units``."""
+        if physical:
+            xi = self.device.coherence_length
+            scale = self.device.current_scale(self.options.current_units)
+            return self.current_through_cut(x0 / xi) / scale * xi
         mesh = self.device.mesh
         em = mesh.edge_mesh
         d = self.tdgl_data
