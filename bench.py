@@ -340,6 +340,20 @@ def main():
                  vcycle_ms=vc_ms, dt_last=float(res["dt"][-1]), **ctx.poisson_stats()),
         kernels=kernels,
     )
+    # per-step aggregate in SURVEY.md section 8(d)'s canonical (unfused, fp64, int32) accounting: the
+    # non-Poisson kernels K1-K4, K6, K7 once plus one K5 PCG iteration (SpMV + 128 n of vector
+    # operations) per iteration actually taken -- what a straightforward implementation would move
+    its = float(res["pcg_iters"].mean())
+    ab_g = algorithmic_bytes(n, m)
+    step_bytes = (ab_g["K1_psi_laplacian_spmv"] + ab_g["K2_psi_update"] + ab_g["K3_supercurrent"] + ab_g["K4_div_rhs"]
+                  + ab_g["K6_normal_current"] + 16 * n + its * (ab_g["K5_pcg_spmv"] + 128 * n))
+    out["step_aggregate"] = dict(
+        canonical_bytes_per_step=int(step_bytes), pcg_iterations=round(its, 2),
+        achieved_gbs=round(step_bytes * steps_per_s / 1e9, 1),
+        frac_of_hbm_peak=round(step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, 4),
+        note="canonical unfused fp64 bytes x steps/s: exceeds what is physically moved wherever kernels are "
+             "fused or operands are stored in 16/32 bits",
+    )
     if use_dd:  # what rank 0 exchanged per step (every rank issues the same sequence)
         out["comm_per_step"] = dict(
             halo_exchanges=round(comm["halos"] / args.steps, 1),
