@@ -451,7 +451,7 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
 // reduce the outcome of the last psi update into d_status (together with the PCG scalars)
 static void publish_status(tdgl_ctx *ctx) {
     const bool psi = ctx->psi_status_pending;
-    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(WAVE), 0, ctx->stream, ctx->d_status.p, ctx->scal.p,
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->d_status.p, ctx->scal.p,
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks);
     ctx->psi_status_pending = false;
