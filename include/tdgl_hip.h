@@ -233,6 +233,10 @@ int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu);
 /* SolverOptions fields + resets the controller state (tentative_dt = dt_init,
  * d_psi_sq_vals = [], Runner.dt = dt_init; solver.py:316-320, runner.py:262). */
 int tdgl_set_controller(tdgl_ctx *ctx, const tdgl_controller *c);
+/* Host-only: np.mean(values[-window:]) in numpy's summation order (pairwise above 128 elements),
+ * the arithmetic of the controller at solver.py:702-704; window == 0 averages the whole list like
+ * Python's `vals[-0:]`.  No device work. */
+double tdgl_host_mean_tail(const double *values, int64_t n, int32_t window);
 /* Probe sites (device.probe_point_indices, solver.py:142, 691-694); n_probe may be 0. */
 int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_probe);
 
@@ -320,6 +324,16 @@ int tdgl_poisson_rhs(tdgl_ctx *ctx, const double *psi, double *rhs);
  * zero-mean solution.  mu_inout holds the initial guess on entry. */
 int tdgl_poisson_solve(tdgl_ctx *ctx, const double *rhs, double *mu_inout, int32_t *iters,
                        double *relres);
+/* The remaining MeshOperators attributes as operator applications (operators.py:282-345):
+ *   psi_gradient @ psi                      [n_edges] complex   (operators.py:87-117, 340-344)
+ *   divergence @ edge_field                 [n_sites]           (operators.py:59-84, 288)
+ *   mu_laplacian @ mu                       [n_sites]           (operators.py:120-185, 285)
+ *   mu_boundary_laplacian @ mu_boundary     [n_sites]           (operators.py:188-230, 286)
+ * so that code written against the reference seam (`ops.divergence @ J`) keeps working. */
+int tdgl_apply_psi_gradient(tdgl_ctx *ctx, const double *psi, double *out);
+int tdgl_apply_divergence(tdgl_ctx *ctx, const double *edge_field, double *out);
+int tdgl_apply_mu_laplacian(tdgl_ctx *ctx, const double *mu, double *out);
+int tdgl_apply_mu_boundary_laplacian(tdgl_ctx *ctx, const double *mu_boundary, double *out);
 /* -(mu_gradient @ mu) (solver.py:519, operators.py:287). */
 int tdgl_normal_current(tdgl_ctx *ctx, const double *mu, double *out);
 /* One application of the AMG V-cycle preconditioner z = M^-1 r on level-0 vectors given in

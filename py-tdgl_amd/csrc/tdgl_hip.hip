@@ -657,6 +657,7 @@ extern "C" int tdgl_set_controller(tdgl_ctx *ctx, const tdgl_controller *c) {
     if (!(c->adaptive_time_step_multiplier > 0 && c->adaptive_time_step_multiplier < 1))
         TDGL_FAIL(ctx, TDGL_ERR_ARG, "adaptive_time_step_multiplier must be in (0, 1) (got %g).",
                   c->adaptive_time_step_multiplier);
+    if (c->adaptive_window < 0) TDGL_FAIL(ctx, TDGL_ERR_ARG, "adaptive_window must be >= 0 (got %d).", c->adaptive_window);
     ctx->ctl = *c;
     ctx->tentative_dt = c->dt_init;                       // solver.py:319
     ctx->dt_cap = c->adaptive ? c->dt_max : c->dt_init;   // solver.py:320
@@ -742,6 +743,77 @@ extern "C" int tdgl_supercurrent(tdgl_ctx *ctx, const double *psi, double *out) 
     launch_edge_currents(ctx, s.c0.p, nullptr, s.r0.p, nullptr);
     HIP_TRY(ctx, hipGetLastError());
     return download_edges(ctx, s.r0.p, out);
+}
+
+// psi_gradient @ psi (operators.py:340-344): [n_edges] complex
+extern "C" int tdgl_apply_psi_gradient(tdgl_ctx *ctx, const double *psi, double *out) {
+    CTX_GUARD(ctx);
+    if (!psi || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (!ctx->have_links) TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "link exponents not set");
+    Scratch s;
+    HIP_TRY(ctx, s.c0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.c1.alloc(ctx->m_pad));
+    TDGL_TRY(upload_sites(ctx, reinterpret_cast<const double2 *>(psi), s.c0));
+    hipLaunchKernelGGL(k_edge_gradient, dim3(grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream, ctx->m, ctx->e0.p,
+                       ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p, s.c0.p, s.c1.p);
+    HIP_TRY(ctx, hipGetLastError());
+    std::vector<double2> tmp(ctx->m);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), s.c1.p, ctx->m * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double2 *o = reinterpret_cast<double2 *>(out);
+    for (int64_t k = 0; k < ctx->m; ++k) o[ctx->edge_perm[k]] = tmp[k];
+    return TDGL_OK;
+}
+
+// divergence @ edge_field (operators.py:59-84): [n_edges] real -> [n_sites]
+extern "C" int tdgl_apply_divergence(tdgl_ctx *ctx, const double *edge_field, double *out) {
+    CTX_GUARD(ctx);
+    if (!edge_field || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (ctx->n_own != ctx->n) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_apply_divergence: single-GPU contexts only");
+    Scratch s;
+    HIP_TRY(ctx, s.r0.alloc(ctx->m_pad));
+    HIP_TRY(ctx, s.r1.alloc(ctx->n_pad));
+    std::vector<double> tmp(ctx->m_pad, 0.0);
+    for (int64_t k = 0; k < ctx->m; ++k) tmp[k] = edge_field[ctx->edge_perm[k]];
+    HIP_TRY(ctx, hipMemcpyAsync(s.r0.p, tmp.data(), ctx->m_pad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_ceff, dim3(grid_for((int64_t)ctx->lap_pat.n_slices * WAVE)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->lap_pat.n_slices, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p, ctx->lap_slot_edge.p,
+                       ctx->lap_slot_w.p, ctx->e_inv_len.p, (const double *)s.r0.p, (const double *)nullptr, s.r1.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return download_sites(ctx, s.r1.p, out);
+}
+
+// mu_laplacian @ mu (operators.py:285)
+extern "C" int tdgl_apply_mu_laplacian(tdgl_ctx *ctx, const double *mu, double *out) {
+    CTX_GUARD(ctx);
+    if (!mu || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    if (ctx->n_own != ctx->n) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_apply_mu_laplacian: single-GPU contexts only");
+    Scratch s;
+    HIP_TRY(ctx, s.r0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, s.r1.alloc(ctx->n_pad));
+    TDGL_TRY(upload_sites(ctx, mu, s.r0));
+    hipLaunchKernelGGL(k_mu_laplacian, dim3(grid_for((int64_t)ctx->lap_pat.n_slices * WAVE)), dim3(BLOCK), 0,
+                       ctx->stream, ctx->lap_pat.n_slices, ctx->lap_pat.n_rows, ctx->lap_pat.slice_off.p,
+                       ctx->lap_pat.cols.p, ctx->lap_slot_w.p, ctx->lap_diag.p, (const double *)s.r0.p, s.r1.p);
+    HIP_TRY(ctx, hipGetLastError());
+    return download_sites(ctx, s.r1.p, out);
+}
+
+// mu_boundary_laplacian @ mu_boundary (operators.py:188-230, unmasked as built at :286)
+extern "C" int tdgl_apply_mu_boundary_laplacian(tdgl_ctx *ctx, const double *mu_boundary, double *out) {
+    CTX_GUARD(ctx);
+    if ((ctx->nb > 0 && !mu_boundary) || !out) TDGL_FAIL(ctx, TDGL_ERR_ARG, "null argument");
+    Scratch s;
+    DevBuf<double> mb;
+    HIP_TRY(ctx, s.r0.alloc(ctx->n_pad));
+    HIP_TRY(ctx, mb.alloc(std::max<int64_t>(ctx->nb, 1)));
+    if (ctx->nb > 0) {
+        HIP_TRY(ctx, hipMemcpyAsync(mb.p, mu_boundary, ctx->nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_boundary_term, dim3(grid_for(ctx->nb)), dim3(BLOCK), 0, ctx->stream, ctx->nb,
+                           ctx->b_s0.p, ctx->b_s1.p, ctx->b_c0.p, ctx->b_c1.p, (const double *)mb.p, s.r0.p);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return download_sites(ctx, s.r0.p, out);
 }
 
 extern "C" int tdgl_normal_current(tdgl_ctx *ctx, const double *mu, double *out) {

@@ -19,6 +19,7 @@ TDGL_ERR_ARG = 2
 TDGL_ERR_PSI_RETRIES = 3
 TDGL_ERR_PCG = 4
 TDGL_ERR_NOT_READY = 5
+TDGL_ERR_SCREENING = 6
 
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)
@@ -153,6 +154,7 @@ SIGNATURES = {
     "tdgl_set_state": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_set_controller": (C.c_int, [_CTX, C.POINTER(Controller)]),
     "tdgl_set_probes": (C.c_int, [_CTX, c_i32p, C.c_int32]),
+    "tdgl_host_mean_tail": (C.c_double, [c_f64p, C.c_int64, C.c_int32]),
     "tdgl_begin_stage": (C.c_int, [_CTX]),
     "tdgl_run": (
         C.c_int,
@@ -182,6 +184,10 @@ SIGNATURES = {
     "tdgl_poisson_rhs": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_poisson_solve": (C.c_int, [_CTX, c_f64p, c_f64p, C.POINTER(C.c_int32), c_f64p]),
     "tdgl_normal_current": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_apply_psi_gradient": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_apply_divergence": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_apply_mu_laplacian": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_apply_mu_boundary_laplacian": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_vcycle": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_time_kernel": (C.c_int, [_CTX, C.c_int32, C.c_int32, c_f64p]),
     "tdgl_profile_enable": (C.c_int, [_CTX, C.c_int32]),

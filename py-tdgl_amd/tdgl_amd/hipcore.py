@@ -470,6 +470,34 @@ class TDGLContext:
         self._chk(self._lib.tdgl_normal_current(self._ctx, p_f64(mu), p_f64(out)))
         return out
 
+    def apply_psi_gradient(self, psi):
+        psi = c128(psi)
+        out = np.empty(self.m, dtype=np.complex128)
+        self._chk(self._lib.tdgl_apply_psi_gradient(self._ctx, p_f64(psi), p_f64(out)))
+        return out
+
+    def apply_divergence(self, edge_field):
+        f = f64(edge_field)
+        if f.shape != (self.m,):
+            raise ValueError(f"divergence acts on edge fields of shape ({self.m},), got {f.shape}")
+        out = np.empty(self.n)
+        self._chk(self._lib.tdgl_apply_divergence(self._ctx, p_f64(f), p_f64(out)))
+        return out
+
+    def apply_mu_laplacian(self, mu):
+        mu = f64(mu)
+        out = np.empty(self.n)
+        self._chk(self._lib.tdgl_apply_mu_laplacian(self._ctx, p_f64(mu), p_f64(out)))
+        return out
+
+    def apply_mu_boundary_laplacian(self, mu_b):
+        mu_b = f64(mu_b)
+        if mu_b.shape != (self.n_boundary,):
+            raise ValueError(f"mu_boundary has shape ({self.n_boundary},), got {mu_b.shape}")
+        out = np.empty(self.n)
+        self._chk(self._lib.tdgl_apply_mu_boundary_laplacian(self._ctx, p_f64(mu_b), p_f64(out)))
+        return out
+
     def psi_update(self, psi, mu, dt):
         """Returns ``(psi_new, abs_sq_new)`` or ``None`` (like solve_for_psi_squared)."""
         psi, mu = c128(psi), f64(mu)

@@ -23,7 +23,10 @@ class _DeviceOperator:
         self.name, self.shape, self._apply = name, shape, apply
 
     def __matmul__(self, x):
-        return self._apply(np.asarray(x))
+        x = np.asarray(x)
+        if x.ndim != 1 or x.shape[0] != self.shape[1]:
+            raise ValueError(f"dimension mismatch: {self.name} is {self.shape[0]}x{self.shape[1]}, operand {x.shape}")
+        return self._apply(x)
 
     def __repr__(self):
         return f"<HIP operator {self.name} {self.shape[0]}x{self.shape[1]}>"
@@ -94,6 +97,10 @@ class MeshOperators:
         n, m = self.ctx.n, self.ctx.m
         ctx = self.ctx
         self.mu_gradient = _DeviceOperator("mu_gradient", (m, n), lambda mu: -ctx.normal_current(mu))
+        self.divergence = _DeviceOperator("divergence", (n, m), ctx.apply_divergence)
+        self.mu_laplacian = _DeviceOperator("mu_laplacian", (n, n), ctx.apply_mu_laplacian)
+        self.mu_boundary_laplacian = _DeviceOperator(
+            "mu_boundary_laplacian", (n, ctx.n_boundary), ctx.apply_mu_boundary_laplacian)
         self.mu_laplacian_lu = lambda rhs: ctx.poisson_solve(rhs)[0]
 
     def set_link_exponents(self, link_exponents: np.ndarray) -> None:
@@ -105,6 +112,7 @@ class MeshOperators:
         n = self.ctx.n
         ctx = self.ctx
         self.psi_laplacian = _DeviceOperator("psi_laplacian", (n, n), ctx.apply_psi_laplacian)
+        self.psi_gradient = _DeviceOperator("psi_gradient", (ctx.m, n), ctx.apply_psi_gradient)
 
     def get_supercurrent(self, psi: np.ndarray):
         """operators.py:385-394."""

@@ -101,5 +101,7 @@ class SolverOptions:
             fail(f"pcg_rtol must be > 0 (got {self.pcg_rtol}).")
         if self.pcg_max_iter < 1 or self.amg_smoothing_sweeps < 1:
             fail("pcg_max_iter and amg_smoothing_sweeps must be >= 1.")
+        if self.adaptive_window < 0:
+            fail(f"adaptive_window must be >= 0 (got {self.adaptive_window}).")
         if self.save_every < 1:
             fail(f"save_every must be >= 1 (got {self.save_every}).")

@@ -379,6 +379,11 @@ class TDGLSolver:
             ctx.set_induced_vector_potential(induced_vector_potential)
         res = ctx.run(1, np.inf)
         out = ctx.get_state()
+        # The identity test above skips the upload when the caller hands back exactly these
+        # arrays; make them read-only so that an in-place edit (seeding a vortex, zeroing a
+        # region) fails loudly instead of being ignored -- edit a copy and pass that.
+        out["psi"].setflags(write=False)
+        out["mu"].setflags(write=False)
         self._device_holds = (out["psi"], out["mu"])
         step_dt = float(res["dt"][0])
         if running_state is not None:

@@ -97,6 +97,55 @@ def test_normal_current_matches_reference_gradient(small_ctx):
     assert max_abs(ctx.normal_current(mu), want) < 1e-13 * np.abs(want).max()
 
 
+def test_operator_seam_matches_reference_matrices(small_ctx):
+    """psi_gradient, divergence, mu_laplacian, mu_boundary_laplacian as operator applications
+    against the reference's own matrices (operators.py:282-345; fixture operators_small)."""
+    ctx, mesh, g = small_ctx
+    rng = np.random.default_rng(11)
+    psi = g["psi"]
+    want = _csr_from_golden(g, "psi_gradient") @ psi
+    assert max_abs(ctx.apply_psi_gradient(psi), want) < 1e-13 * np.abs(want).max()
+    f = rng.normal(size=ctx.m)
+    want = _csr_from_golden(g, "divergence") @ f
+    assert max_abs(ctx.apply_divergence(f), want) < 1e-13 * np.abs(want).max()
+    mu = rng.normal(size=ctx.n)
+    want = _csr_from_golden(g, "mu_laplacian") @ mu
+    assert max_abs(ctx.apply_mu_laplacian(mu), want) < 1e-13 * np.abs(want).max()
+    mb = rng.normal(size=ctx.n_boundary)
+    want = _csr_from_golden(g, "mu_boundary_laplacian") @ mb
+    assert max_abs(ctx.apply_mu_boundary_laplacian(mb), want) < 1e-13 * np.abs(want).max()
+
+
+def test_mesh_operators_exposes_the_reference_attributes():
+    """Code written against the reference seam: `ops.divergence @ J`, `ops.mu_laplacian @ mu`, ...
+    (operators.py:282-299, 340-344)."""
+    from tdgl_amd.operators import MeshOperators
+
+    g = load_golden("operators_small")
+    mesh = reference_mesh(load_golden("mesh_small"))
+    ops = MeshOperators(mesh, fixed_sites=g["fixed_sites"], fix_psi=True)
+    ops.build_operators()
+    ops.set_link_exponents(g["A"])
+    for name in ("psi_laplacian", "psi_gradient", "divergence", "mu_laplacian", "mu_boundary_laplacian",
+                 "mu_gradient", "mu_laplacian_lu"):
+        assert getattr(ops, name) is not None, name
+    psi = g["psi"]
+    js = ops.get_supercurrent(psi)
+    assert max_abs(js, g["supercurrent"]) < 1e-13
+    grad = ops.psi_gradient @ psi
+    assert max_abs((psi.conj()[mesh.edge_mesh.edges[:, 0]] * grad).imag, js) < 1e-13
+    want = _csr_from_golden(g, "divergence") @ js
+    assert max_abs(ops.divergence @ js, want) < 1e-13 * max(1.0, np.abs(want).max())
+    assert ops.divergence.shape == (len(mesh.sites), len(mesh.edge_mesh.edges))
+    with pytest.raises(ValueError):
+        ops.divergence @ psi  # wrong length
+    # mu_laplacian_lu inverts mu_laplacian up to the constant
+    rhs = ops.mu_laplacian @ np.cos(mesh.sites[:, 0] / 3.0)
+    mu = ops.mu_laplacian_lu(rhs)
+    assert max_abs(ops.mu_laplacian @ mu, rhs) < 1e-8 * np.abs(rhs).max()
+    ops.ctx.close()
+
+
 def test_poisson_rhs_matches_divergence_of_supercurrent(small_ctx):
     ctx, mesh, g = small_ctx
     rng = np.random.default_rng(5)

@@ -349,3 +349,23 @@ def test_amg_hierarchy_and_host_pcg():
     # determinism of the set-up (hashed priorities)
     h2 = build_hierarchy(A, max_coarse=200)
     assert h2.sizes == h.sizes and abs(h2.levels[0].P - h.levels[0].P).max() == 0
+
+
+def test_controller_mean_reproduces_numpy_summation_order():
+    """The dt controller averages `d_psi_sq_vals[-window:]` with np.mean (solver.py:702-704); the
+    library's host helper must give the same bits, also beyond numpy's 128-element block where the
+    sum is split recursively, and `window == 0` must select the whole list like Python's `[-0:]`."""
+    import ctypes as C
+
+    from tdgl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    vals = (rng.random(3000) * 10.0 ** rng.integers(-12, 0, 3000)).tolist()
+    for size in (1, 5, 8, 9, 17, 127, 128, 129, 200, 1000, 3000):
+        for window in (0, 1, 7, 10, 128, 129, 257, 1024, 5000):
+            v = vals[:size]
+            want = float(np.mean(v[-window:]))
+            arr = np.ascontiguousarray(v, dtype=np.float64)
+            got = lib.tdgl_host_mean_tail(arr.ctypes.data_as(C.POINTER(C.c_double)), len(arr), window)
+            assert got == want, (size, window, got, want)
