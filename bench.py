@@ -3,17 +3,27 @@
 mesh; achieved HBM GB/s vs roofline").
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...          # N > 1 without a launcher: spawns its own N ranks
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one call of the reference's ``TDGLSolver.update`` (psi update with retries, Poisson
 solve for mu, supercurrent + normal current on every edge, probe read-out, adaptive-dt
 controller) on a synthetic square film in a uniform field, fields resident in HBM.  Prints ONE
 JSON line on rank 0.  See DESIGN.md "Measurement" for the byte accounting.
+
+Steady state: whatever ``--warmup`` says, the run first takes ``--preroll`` untimed steps (default
+200) so that the timed window sits where the adaptive time step has opened up and the Poisson
+solve needs its steady ~14 iterations -- the first ~100 steps of the trajectory are cheaper and
+not representative.
 """
 
 import argparse
+import glob
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -29,6 +39,7 @@ for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "tdgl_steps_per_sec"
 
 WORKLOADS = {
     # name: (side in xi, description)           site counts follow SURVEY.md §8(d)
@@ -36,17 +47,11 @@ WORKLOADS = {
     "60k": (226.0, "square film 226 xi, 59,377 sites"),
     "250k": (465.0, "square film 465 xi, 250,510 sites"),
     "1M": (930.0, "square film 930 xi, 1,000,431 sites"),
-    "4M": (1860.0, "square film 1860 xi, ~4.0M sites"),
+    "4M": (1860.0, "square film 1860 xi, 3,998,502 sites"),
     # BASELINE config 4: strip with two current terminals (short edges), I = 0.2 * Ly, zero field
-    "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 500,955 sites, two current terminals, I = 0.2 Ly"),
+    "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly"),
 }
 B_FIELD = 0.1  # B / Bc2
-
-# HBM bytes per launch of the fused psi-Laplacian kernel from rocprofv3 PMC counters
-# ((2 * FETCH_SIZE + WRITE_SIZE) KiB, gfx950 correction calibrated on a copy kernel in the same
-# run: profiles/r01h_pmc_hbm_traffic_1M.txt).  Counters cannot be read inside this process.
-PMC_TRAFFIC_BYTES = {"1M": 175.7e6}
-PMC_TRAFFIC_AXP_BYTES = {"1M": 98.0e6}
 
 
 def log(*a):
@@ -70,8 +75,25 @@ def algorithmic_bytes(n, m):
         "K4_div_rhs": 32 * m + 12 * n,
         "K5_pcg_spmv": 12 * nnz + 20 * n,
         "K6_normal_current": 36 * m + 8 * n,
-        "copy_c128": 32 * n,
     }
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the rocprofv3 PMC passes of the CURRENT kernels: the newest
+    ``profiles/r*_pmc_hbm_traffic_<workload>.json`` (written by tools/rocpd_pmc.py from two
+    ``--pmc`` passes of this very command; counters cannot be read inside the process)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{workload}.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        return json.load(f)["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+
+
+def traffic_of(table, prefix):
+    for name, nbytes in table.items():
+        if name.startswith(prefix):
+            return float(nbytes)
+    return None
 
 
 def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, terms=(), currents=None):
@@ -110,11 +132,83 @@ def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, term
     )
 
 
+def build_workload(name):
+    """Synthetic mesh + inputs of one workload."""
+    from tdgl_amd.finite_volume import Mesh
+    from tdgl_amd.meshgen import hex_jitter_points, triangulate
+
+    side, desc = WORKLOADS[name]
+    t0 = time.perf_counter()
+    strip = isinstance(side, tuple)
+    pts = hex_jitter_points(*side) if strip else hex_jitter_points(side, side)
+    mesh = Mesh.from_triangulation(pts, triangulate(pts))
+    n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
+    log(f"workload {name}: mesh {n} sites / {m} edges in {time.perf_counter() - t0:.1f} s")
+    A = uniform_A(mesh, 0.0 if strip else B_FIELD)
+    terms, currents = (), None
+    if strip:
+        em_ = mesh.edge_mesh
+        bidx = em_.boundary_edge_indices
+
+        def terminal(tname, x0):
+            pos = np.flatnonzero(np.isclose(em_.centers[bidx, 0], x0))
+            return dict(name=tname, boundary_edge_indices=pos, edge_indices=bidx[pos],
+                        length=em_.edge_lengths[bidx][pos].sum(),
+                        site_indices=np.intersect1d(np.flatnonzero(np.isclose(mesh.sites[:, 0], x0)), mesh.boundary_indices))
+
+        terms = [terminal("source", -side[0] / 2), terminal("drain", side[0] / 2)]
+        currents = {"source": 0.2 * side[1], "drain": -0.2 * side[1]}
+    return SimpleNamespace(name=name, desc=desc, strip=strip, mesh=mesh, A=A, terms=terms, currents=currents, n=n, m=m)
+
+
+OPT_KW = dict(solve_time=1e12, dt_init=1e-4, dt_max=0.1, adaptive=True, adaptive_window=10,
+              max_solve_retries=10, adaptive_time_step_multiplier=0.25, save_every=10**9)
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` without a launcher: become the launcher.  One child per GPU with
+    the torch.distributed.run environment; rank 0's stdout (the JSON line) passes through."""
+    from tdgl_amd import _lib as _tdgl_lib
+
+    have = _tdgl_lib.device_count()
+    if have < args.gpus:
+        print(json.dumps(dict(metric=METRIC, value=None, unit="steps/s", n_gpus=args.gpus, steps=args.steps,
+                              warmup=args.warmup, higher_is_better=True,
+                              error=f"needs {args.gpus} devices, found {have}")), flush=True)
+        return 0
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    deadline = time.time() + (args.timeout + 60 if args.timeout > 0 else 10**9)
+    rc = 0
+    try:
+        for pr in procs:
+            rc = max(rc, abs(pr.wait(timeout=max(1.0, deadline - time.time()))))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)  # exactly the process groups started above
+                except ProcessLookupError:
+                    pass
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll", type=int, default=200,
+                    help="untimed steps before the warm-up, so that the timed window is the steady state whatever --warmup is")
     ap.add_argument("--workload", default=os.environ.get("TDGL_BENCH_WORKLOAD", "1M"), choices=list(WORKLOADS))
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--check-every", type=int, default=0, help="0 = auto (predicted)")
@@ -129,139 +223,220 @@ def main():
                     help="restrict the level-0 residual with two kernels instead of the pre-multiplied operator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the domain-decomposition driver (RCCL communicator) even on one GPU")
+    ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
+                    help="also run BASELINE config 5 (4M-site film, same decomposition) and report it as `config5`; "
+                         "auto = when more than one GPU is used")
+    ap.add_argument("--trace-iterations", default=None,
+                    help="write dt / PCG iterations of every step (pre-roll included) to this .json file")
     ap.add_argument("--timeout", type=int, default=1500,
                     help="hard limit in seconds for the whole run (SIGALRM ends a hung rank instead of blocking the node); 0 = none")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
     if args.timeout > 0:
-        import signal
-
         signal.alarm(args.timeout)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # load libtdgl_hip (and with it ROCm 7.2's HIP runtime + RCCL) before torch brings its own
     from tdgl_amd import _lib as _tdgl_lib
 
     _tdgl_lib.load()
+    use_dd = world > 1 or args.force_distributed
     dist = None
-    if world > 1:
+    if use_dd:
         import torch.distributed as dist_mod
 
         from tdgl_amd.distributed import stdout_to_stderr
 
         dist = dist_mod
-        with stdout_to_stderr():  # gloo / RCCL print banners on stdout; stdout is the JSON line
-            dist.init_process_group("gloo")  # bootstrap, barrier, max-reduce; the data path is RCCL
-
-    from tdgl_amd import SolverOptions, TDGLSolver
-    from tdgl_amd.finite_volume import Mesh
-    from tdgl_amd.meshgen import hex_jitter_points, triangulate
-
-    side, desc = WORKLOADS[args.workload]
-    t0 = time.perf_counter()
-    strip = isinstance(side, tuple)
-    pts = hex_jitter_points(*side) if strip else hex_jitter_points(side, side)
-    tri = triangulate(pts)
-    mesh = Mesh.from_triangulation(pts, tri)
-    n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
-    log(f"rank {rank}: mesh {n} sites / {m} edges in {time.perf_counter() - t0:.1f} s")
-    A = uniform_A(mesh, 0.0 if strip else B_FIELD)
-    terms, currents = (), None
-    if strip:
-        em_ = mesh.edge_mesh
-        bidx = em_.boundary_edge_indices
-
-        def terminal(name, x0):
-            pos = np.flatnonzero(np.isclose(em_.centers[bidx, 0], x0))
-            return dict(name=name, boundary_edge_indices=pos, edge_indices=bidx[pos],
-                        length=em_.edge_lengths[bidx][pos].sum(),
-                        site_indices=np.intersect1d(np.flatnonzero(np.isclose(mesh.sites[:, 0], x0)), mesh.boundary_indices))
-
-        terms = [terminal("source", -side[0] / 2), terminal("drain", side[0] / 2)]
-        currents = {"source": 0.2 * side[1], "drain": -0.2 * side[1]}
-        if world > 1:
-            raise SystemExit("the strip workload is single-GPU in bench.py")
-    opt_kw = dict(solve_time=1e12, dt_init=1e-4, dt_max=0.1, adaptive=True, adaptive_window=10,
-                  max_solve_retries=10, adaptive_time_step_multiplier=0.25, save_every=10**9)
-    opts = SolverOptions(**opt_kw, pcg_rtol=args.rtol, edge_currents_every_step=True, device_id=local_rank)
-    t0 = time.perf_counter()
-    psi_init, mu_init = np.ones(n, dtype=np.complex128), np.zeros(n)
-    use_dd = world > 1 or args.force_distributed
-    if use_dd and dist is None:
-        import torch.distributed as dist_mod
-
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        from tdgl_amd.distributed import stdout_to_stderr
+        with stdout_to_stderr():  # gloo / RCCL print banners on stdout; stdout is the JSON line
+            dist.init_process_group("gloo", rank=rank, world_size=world)  # bootstrap, barrier, max-reduce; the data path is RCCL
 
-        with stdout_to_stderr():
-            dist_mod.init_process_group("gloo", rank=0, world_size=1)
-    if not use_dd:
-        solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0, terminal_info=terms, current_func=currents)
-        solver.update_mu_boundary(0.0)
-        psi_init = solver.psi_init
-        ctx = solver.ctx
-        n_loc, m_loc = n, m
-        ctx.set_state(psi_init, mu_init)
-    else:
-        # ONE simulation cut into `world` pieces (strong scaling of the N=1 workload): RCB
-        # partition, RCCL halo exchange + all-reduces inside tdgl_run
-        from tdgl_amd.distributed import DistributedTDGL
+    from tdgl_amd import SolverOptions, TDGLSolver
 
-        drun = DistributedTDGL(mesh, opts, A, 1.0, rank=rank, world=world, transport="rccl", device_id=local_rank)
-        ctx = drun.ctx
-        n_loc, m_loc = drun.lp.n_own, len(drun.lp.edge_local_to_global)
-        drun.set_state(psi_init, mu_init)
-        log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
-    ctx.set_poisson_options(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
-                            edge_currents_every_step=True, smoother=args.smoother,
-                            extrapolate=args.extrapolate, nu_fine=args.nu_fine,
-                            fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
-                            precond_fp32=not args.precond_fp64)
-    h = ctx.hierarchy
-    log(f"rank {rank}: device setup {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, operator complexity {h.operator_complexity:.2f}")
-    ctx.begin_stage()
+    opts = SolverOptions(**OPT_KW, pcg_rtol=args.rtol, edge_currents_every_step=True, device_id=local_rank)
+    popt = dict(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
+                edge_currents_every_step=True, smoother=args.smoother, extrapolate=args.extrapolate,
+                nu_fine=args.nu_fine, fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
+                precond_fp32=not args.precond_fp64)
 
-    def barrier():
-        ctx.synchronize()
+    def run_workload(name, want_cpu_state):
+        """Set up `name`, pre-roll + warm up, time K steps.  Returns a dict of measurements (rank 0
+        holds the global mesh; in decomposed runs the other ranks receive their pieces from it)."""
+        t0 = time.perf_counter()
+        wl = build_workload(name) if (rank == 0 or not use_dd) else None
+        if wl is not None and wl.strip and use_dd:
+            raise SystemExit("the strip workload is single-GPU in bench.py")
+        drun = None
+        if not use_dd:
+            solver = TDGLSolver.from_dimensionless(wl.mesh, opts, wl.A, 1.0, terminal_info=wl.terms, current_func=wl.currents)
+            solver.update_mu_boundary(0.0)
+            ctx = solver.ctx
+            n_loc, m_loc, n, m = wl.n, wl.m, wl.n, wl.m
+            ctx.set_state(solver.psi_init, np.zeros(wl.n))
+        else:
+            # ONE simulation cut into `world` pieces (strong scaling): RCB partition, RCCL halo exchange
+            # + all-reduces inside tdgl_run (DESIGN.md section 6).  Rank 0 meshes, partitions and builds
+            # the AMG hierarchy once and scatters the pieces.
+            from tdgl_amd.distributed import DistributedTDGL
+
+            drun = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
+                                   rank=rank, world=world, transport="rccl", device_id=local_rank, root=0)
+            ctx = drun.ctx
+            n_loc, m_loc, n, m = drun.lp.n_own, len(drun.lp.edge_local_to_global), drun.n_global, drun.m_global
+            drun.set_state(1.0, 0.0)
+            log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
+        ctx.set_poisson_options(**popt)
+        h = ctx.hierarchy
+        log(f"rank {rank}: {name} set-up {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, "
+            f"operator complexity {h.operator_complexity:.2f}")
+        ctx.begin_stage()
+
+        def barrier():
+            ctx.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        trace = []
+        if args.preroll > 0:
+            trace.append(ctx.run(args.preroll))
+        if args.warmup > 0:
+            trace.append(ctx.run(args.warmup))
+        barrier()
+        start_state = None
+        if want_cpu_state:
+            st = ctx.get_state(supercurrent=False, normal_current=False)
+            ls = ctx.loop_state()
+            start_state = dict(psi=st["psi"], mu=st["mu"], time=ls["time"], dt=ls["dt"], tentative_dt=ls["tentative_dt"])
+        # ---- timed region: exactly K steps ---------------------------------------------------
+        ctx.profile_enable(True)
+        ctx.comm_stats(reset=True)
+        barrier()
+        t_begin = time.perf_counter()
+        res = ctx.run(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t_begin
+        assert len(res["dt"]) == args.steps
+        trace.append(res)
+        launches, k1_ms = ctx.profile_read()
+        axp_launches, axp_ms = ctx.profile_read_pcg() if not use_dd else (0, 0.0)
+        ctx.profile_enable(False)
+        comm = ctx.comm_stats()
         if dist is not None:
-            dist.barrier()
+            import torch
 
-    # ---- warm-up (untimed) -------------------------------------------------------------
-    warm = ctx.run(args.warmup) if args.warmup > 0 else None
-    barrier()
-    start_state = None
-    if rank == 0 and not use_dd and not args.no_cpu_baseline:
-        st = ctx.get_state(supercurrent=False, normal_current=False)
-        ls = ctx.loop_state()
-        start_state = dict(psi=st["psi"], mu=st["mu"], time=ls["time"], dt=ls["dt"], tentative_dt=ls["tentative_dt"])
+            tmax = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        out = SimpleNamespace(
+            wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
+            k1=(launches, k1_ms), axp=(axp_launches, axp_ms), comm=comm, sizes=list(h.sizes), start_state=start_state,
+            stats=ctx.poisson_stats(), overlap=ctx.comm_overlap() if use_dd else None,
+            its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
+            trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
+                       pcg_iters=np.concatenate([t["pcg_iters"] for t in trace]).tolist()),
+        )
+        return out
 
-    # ---- timed region: exactly K steps -----------------------------------------------------
-    ctx.profile_enable(True)
-    ctx.comm_stats(reset=True)
-    barrier()
-    t_begin = time.perf_counter()
-    res = ctx.run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t_begin
-    assert len(res["dt"]) == args.steps
-    launches, k1_ms = ctx.profile_read()
-    axp_launches, axp_ms = ctx.profile_read_pcg() if not use_dd else (0, 0.0)
-    ctx.profile_enable(False)
-    comm = ctx.comm_stats()
-    if dist is not None:
-        import torch
+    main_run = run_workload(args.workload, want_cpu_state=(rank == 0 and not use_dd and not args.no_cpu_baseline))
+    if args.trace_iterations and rank == 0:
+        with open(args.trace_iterations, "w") as f:
+            json.dump(dict(workload=args.workload, preroll=args.preroll, warmup=args.warmup, steps=args.steps,
+                           **main_run.trace), f)
 
-        tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def roofline_k1(r):
+        ab = algorithmic_bytes(r.n_loc, r.m_loc)  # the kernel rank 0 launches covers its own rows
+        launches, k1_ms = r.k1
+        avg = k1_ms / max(launches, 1)
+        achieved = ab["K1_psi_laplacian_spmv"] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        table, src = pmc_traffic(r.name) if not use_dd else ({}, None)
+        return dict(
+            bound="hbm",
+            kernel="k_psi_laplacian<true> (SELL-64 covariant-Laplacian SpMV fused with the Poisson right-hand side)"
+                   + (f"; rank 0's {r.n_loc} owned rows" if use_dd else ""),
+            achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+            traffic=traffic_of(table, "void tdgl::k_psi_laplacian<true"),
+            traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
+            algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"], avg_launch_ms=round(avg, 5), launches=launches,
+        )
+
+    def line_for(r):
+        steps_per_s = args.steps / r.elapsed  # one simulation, whatever the number of GPUs
+        its = float(r.res["pcg_iters"].mean())
+        ab_g = algorithmic_bytes(r.n, r.m)
+        step_bytes = (ab_g["K1_psi_laplacian_spmv"] + ab_g["K2_psi_update"] + ab_g["K3_supercurrent"] + ab_g["K4_div_rhs"]
+                      + ab_g["K6_normal_current"] + 16 * r.n + its * (ab_g["K5_pcg_spmv"] + 128 * r.n))
+        d = dict(
+            value=round(steps_per_s, 3), ms_per_step=round(1e3 * r.elapsed / args.steps, 4), sites=r.n, edges=r.m,
+            amg_levels=r.sizes,
+            pcg=dict(mean_iterations=round(its, 2), max_iterations=int(r.res["pcg_iters"].max()),
+                     mean_iterations_untimed=None if r.its_pre is None else round(r.its_pre, 2),
+                     dt_last=float(r.res["dt"][-1]), **r.stats),
+            roofline=roofline_k1(r),
+            # per-step aggregate in SURVEY.md section 8(d)'s canonical (unfused, fp64, int32) accounting: the
+            # non-Poisson kernels K1-K4, K6, K7 once plus one K5 PCG iteration (SpMV + 128 n of vector
+            # operations) per iteration actually taken -- what a straightforward implementation would move
+            step_aggregate=dict(
+                canonical_bytes_per_step=int(step_bytes), pcg_iterations=round(its, 2),
+                achieved_gbs=round(step_bytes * steps_per_s / 1e9, 1),
+                frac_of_hbm_peak=round(step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                note="canonical unfused fp64 bytes x steps/s: exceeds what is physically moved wherever kernels are "
+                     "fused or operands are stored in 16/32 bits",
+            ),
+        )
+        if use_dd:  # what rank 0 exchanged per step (every rank issues the same sequence)
+            d["comm_per_step"] = dict(
+                halo_exchanges=round(r.comm["halos"] / args.steps, 1),
+                halo_bytes_sent=int(r.comm["halo_bytes"] / args.steps),
+                allreduces=round(r.comm["allreduces"] / args.steps, 1),
+                allreduce_bytes=int(r.comm["allreduce_bytes"] / args.steps),
+                neighbours=len(r.drun.lp.neighbors), ghost_sites=int(r.drun.lp.n_ghost),
+                overlap=bool(r.overlap[0]), interior_rows=int(r.overlap[1]),
+            )
+        return d
+
+    main_line = line_for(main_run) if rank == 0 else None
+    # the kernel that dominates the run time: the CG's fused direction update + A p (k_sell_axp), timed
+    # in the run on its first 256 launches; algorithmic bytes = K5 SpMV + the direction update's 24 n
+    roofline_pcg = None
+    if rank == 0 and main_run.axp[0] > 0:
+        ab = algorithmic_bytes(main_run.n_loc, main_run.m_loc)
+        axp_alg = ab["K5_pcg_spmv"] + 24 * main_run.n_loc
+        axp_avg_ms = main_run.axp[1] / main_run.axp[0]
+        table, src = pmc_traffic(main_run.name)
+        roofline_pcg = dict(
+            bound="hbm",
+            kernel="k_sell_axp (CG direction update p = z + beta p fused with q = A p and the p.q partials; "
+                   "one launch per PCG iteration, the largest single share of the run time)",
+            achieved=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            traffic=traffic_of(table, "void tdgl::k_sell_axp"),
+            traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
+            algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=main_run.axp[0],
+        )
+    # BASELINE config 5 next to the headline workload (decomposed runs)
+    config5 = None
+    want5 = args.config5 == "on" or (args.config5 == "auto" and world > 1)
+    if want5 and args.workload != "4M":
+        start_state_keep, wl_keep = main_run.start_state, main_run.wl
+        if main_run.drun is not None:
+            main_run.drun.close()
+        else:
+            main_run.ctx.close()
+        r5 = run_workload("4M", want_cpu_state=False)
+        if rank == 0:
+            l5 = line_for(r5)
+            config5 = dict(workload=f"{WORKLOADS['4M'][1]}, same options and decomposition (BASELINE config 5)",
+                           scaling="strong", **l5)
+        main_run.start_state, main_run.wl = start_state_keep, wl_keep
 
     if rank != 0:
         if dist is not None:
@@ -269,57 +444,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    steps_per_s = args.steps / elapsed  # one simulation, whatever the number of GPUs
-    ab = algorithmic_bytes(n_loc, m_loc)  # the kernel rank 0 launches covers its own rows
-    k1_avg_ms = k1_ms / max(launches, 1)
-    achieved = ab["K1_psi_laplacian_spmv"] / (k1_avg_ms * 1e-3) / 1e9
-    roofline = dict(
-        bound="hbm",
-        kernel="k_psi_laplacian<true> (SELL-64 covariant-Laplacian SpMV fused with the Poisson right-hand side)",
-        achieved=round(achieved, 1),
-        peak=HBM_PEAK_GBS,
-        unit="GB/s",
-        frac=round(achieved / HBM_PEAK_GBS, 4),
-        traffic=PMC_TRAFFIC_BYTES.get(args.workload) if not use_dd else None,
-        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01h_pmc_hbm_traffic_1M.txt",
-        algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"],
-        avg_launch_ms=round(k1_avg_ms, 5),
-        launches=launches,
-    )
-    # the kernel that dominates the run time: the CG's fused direction update + A p (k_sell_axp), timed
-    # in the run on the first 256 launches; algorithmic bytes = K5 SpMV + the direction update's 24 n
-    roofline_pcg = None
-    if axp_launches > 0:
-        axp_alg = ab["K5_pcg_spmv"] + 24 * n_loc
-        axp_avg_ms = axp_ms / axp_launches
-        roofline_pcg = dict(
-            bound="hbm",
-            kernel="k_sell_axp (CG direction update p = z + beta p fused with q = A p and the p.q partials; "
-                   "one launch per PCG iteration, the largest single share of the run time)",
-            achieved=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-            frac=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            traffic=PMC_TRAFFIC_AXP_BYTES.get(args.workload),
-            traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01h_pmc_hbm_traffic_1M.txt",
-            algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=axp_launches,
-        )
-    # stand-alone kernel timings (same buffers, back-to-back launches) for the other rows
-    names = {0: "K1_psi_laplacian_spmv", 2: "K2_psi_update", 3: "K3_supercurrent", 4: "K5_pcg_spmv", 6: "copy_c128"}
-    kernels = {}
-    for kid, name in (names.items() if not use_dd else []):
-        ms = ctx.time_kernel(kid, args.kernel_reps)
-        nbytes = ab[name] + (ab["K6_normal_current"] if kid == 3 else 0)
-        kernels[name if kid != 3 else "K3+K6_edge_currents"] = dict(
-            ms=round(ms, 5), gbs=round(nbytes / (ms * 1e-3) / 1e9, 1), frac=round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        )
-    vc_ms = round(ctx.time_kernel(5, 20), 4) if not use_dd else None
+    r = main_run
+    desc = WORKLOADS[args.workload][1]
+    strip = isinstance(WORKLOADS[args.workload][0], tuple)
     out = dict(
-        metric="tdgl_steps_per_sec",
-        value=round(steps_per_s, 3),
+        metric=METRIC,
+        value=main_line["value"],
         unit="steps/s",
         n_gpus=world,
         steps=args.steps,
         warmup=args.warmup,
-        ms_per_step=round(1e3 * elapsed / args.steps, 4),
+        ms_per_step=main_line["ms_per_step"],
         higher_is_better=True,
         scaling="strong",
         vs_baseline=None,
@@ -329,45 +464,27 @@ def main():
             workload=f"{desc}, " + ("" if strip else f"uniform field b=B/Bc2={B_FIELD}, ") + f"adaptive dt (dt_init 1e-4, dt_max 0.1), "
                      f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
                      + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32, all arithmetic and the CG in fp64")
-                     + "), J_s/J_n formed every step",
-            sites=n, edges=m, amg_levels=h.sizes,
+                     + f"), J_s/J_n formed every step; steady state: {args.preroll} pre-roll + {args.warmup} warm-up steps "
+                       f"untimed, then {args.steps} timed steps at {main_line['pcg']['mean_iterations']} PCG iterations per step",
+            sites=r.n, edges=r.m, amg_levels=r.sizes, preroll=args.preroll,
             parallelism="single" if world == 1 else
-            f"domain decomposition (RCB, {world} ranks, ~{n // world} sites each), RCCL halo exchange + all-reduce",
+            f"domain decomposition (RCB, {world} ranks, ~{r.n // world} sites each), RCCL halo exchange + all-reduce",
         ),
-        roofline=roofline,
+        roofline=main_line["roofline"],
         roofline_pcg=roofline_pcg,
-        pcg=dict(mean_iterations=round(float(res["pcg_iters"].mean()), 2), max_iterations=int(res["pcg_iters"].max()),
-                 vcycle_ms=vc_ms, dt_last=float(res["dt"][-1]), **ctx.poisson_stats()),
-        kernels=kernels,
+        pcg=main_line["pcg"],
+        step_aggregate=main_line["step_aggregate"],
     )
-    # per-step aggregate in SURVEY.md section 8(d)'s canonical (unfused, fp64, int32) accounting: the
-    # non-Poisson kernels K1-K4, K6, K7 once plus one K5 PCG iteration (SpMV + 128 n of vector
-    # operations) per iteration actually taken -- what a straightforward implementation would move
-    its = float(res["pcg_iters"].mean())
-    ab_g = algorithmic_bytes(n, m)
-    step_bytes = (ab_g["K1_psi_laplacian_spmv"] + ab_g["K2_psi_update"] + ab_g["K3_supercurrent"] + ab_g["K4_div_rhs"]
-                  + ab_g["K6_normal_current"] + 16 * n + its * (ab_g["K5_pcg_spmv"] + 128 * n))
-    out["step_aggregate"] = dict(
-        canonical_bytes_per_step=int(step_bytes), pcg_iterations=round(its, 2),
-        achieved_gbs=round(step_bytes * steps_per_s / 1e9, 1),
-        frac_of_hbm_peak=round(step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, 4),
-        note="canonical unfused fp64 bytes x steps/s: exceeds what is physically moved wherever kernels are "
-             "fused or operands are stored in 16/32 bits",
-    )
-    if use_dd:  # what rank 0 exchanged per step (every rank issues the same sequence)
-        out["comm_per_step"] = dict(
-            halo_exchanges=round(comm["halos"] / args.steps, 1),
-            halo_bytes_sent=int(comm["halo_bytes"] / args.steps),
-            allreduces=round(comm["allreduces"] / args.steps, 1),
-            allreduce_bytes=int(comm["allreduce_bytes"] / args.steps),
-            neighbours=len(drun.lp.neighbors), ghost_sites=int(drun.lp.n_ghost),
-            overlap=bool(ctx.comm_overlap()[0]), interior_rows=int(ctx.comm_overlap()[1]),
-        )
-    if start_state is not None:
+    if "comm_per_step" in main_line:
+        out["comm_per_step"] = main_line["comm_per_step"]
+    if config5 is not None:
+        out["config5"] = config5
+    if r.start_state is not None:
         log("timing the CPU oracle (LU factorisation first; this takes a while at 1M sites)")
-        out["cpu_baseline"] = cpu_baseline(mesh, A, start_state, opt_kw, target_seconds=args.cpu_seconds,
-                                           terms=terms, currents=currents)
-        out["speedup_vs_cpu_baseline"] = round(steps_per_s / out["cpu_baseline"]["value"], 1)
+        wl = r.wl
+        out["cpu_baseline"] = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
+                                           terms=wl.terms, currents=wl.currents)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
         out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -9,8 +9,9 @@ Usage (every rank of a `torch.distributed` job runs the same code):
     out = run.run(100)                       # identical dt sequence on every rank
     fields = run.gather_state()              # global psi, mu, J_s, J_n on every rank
 
-The mesh is cut by recursive coordinate bisection (`partition.rcb_partition`), every rank builds
-the same global AMG hierarchy and uploads its slice.  The exchange of ghost values and the
+The mesh is cut by recursive coordinate bisection (`partition.rcb_partition`).  With ``root=0`` only
+rank 0 holds the global mesh: it builds the partition and the AMG hierarchy once and scatters each
+rank's piece (`prepare_payloads`); without it every rank cuts its own piece from the global mesh.  The exchange of ghost values and the
 all-reduces run inside `tdgl_run` over RCCL on the context's stream (transport "rccl"); transport
 "gloo" routes them through host callbacks and torch.distributed instead -- slow, used by the test
 suite so that several ranks can share one GPU.
@@ -27,7 +28,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL 
 
 from .amg import build_hierarchy
 from .hipcore import TDGLContext, poisson_matrix
-from .partition import build_local_problem, rcb_partition
+from .partition import build_local_problem, local_hierarchy_level0, rcb_partition
 
 
 @contextlib.contextmanager
@@ -47,10 +48,83 @@ def stdout_to_stderr():
         os.close(saved)
 
 
+def prepare_payloads(mesh, world, link_exponents, epsilon=1.0, **kw):
+    """`prepare_payloads_for` all ranks."""
+    return prepare_payloads_for(mesh, world, range(int(world)), link_exponents, epsilon, **kw)
+
+
+def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, terminal_info=(), mu_boundary=None,
+                         probe_points=None, screening=None, max_coarse=None, hierarchy=None):
+    """Everything the ranks of a `world`-way run need, computed ONCE (by the root rank or ahead of
+    time): the partition, each rank's sub-mesh + halo plan, its slice of AMG level 0 and of the
+    inputs, and the coarse levels (replicated, one shared object).  Returns a list of `world`
+    dicts; `DistributedTDGL(payload=...)` consumes one.  The counterpart of the reference's
+    single `MeshOperators.build_operators()` (operators.py:282-308) for a decomposed mesh."""
+    em = mesh.edge_mesh
+    n, m = len(mesh.sites), len(em.edges)
+    fixed = (
+        np.concatenate([np.asarray(t["site_indices"] if isinstance(t, dict) else t.site_indices)
+                        for t in terminal_info]).astype(np.int64)
+        if len(terminal_info) else np.array([], dtype=np.int64)
+    )
+    part = rcb_partition(mesh.sites, int(world))
+    if hierarchy is None:
+        A_glob = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
+        # (level 0 is the distributed one, so the hierarchy needs at least one coarser level)
+        hierarchy = build_hierarchy(A_glob, max_coarse=max_coarse or min(600, max(8, n // 4)))
+    coarse = dict(levels=list(hierarchy.levels[1:]), coarse_pinv=hierarchy.coarse_pinv,
+                  sizes=hierarchy.sizes, operator_complexity=hierarchy.operator_complexity)
+    A_e = np.asarray(link_exponents, dtype=float)
+    eps = np.asarray(epsilon, dtype=float) * np.ones(n)
+    mu_b = np.zeros(len(em.boundary_edge_indices)) if mu_boundary is None else np.asarray(mu_boundary, dtype=float)
+    probes = None if probe_points is None else np.asarray(probe_points, dtype=np.int64)
+    out = []
+    for r in ranks:
+        lp = build_local_problem(mesh, part, r, fixed_sites=fixed)
+        l2g = lp.local_to_global
+        pay = dict(
+            rank=r, world=int(world), n_global=n, m_global=m, lp=lp, level0=local_hierarchy_level0(hierarchy, lp),
+            coarse=coarse, link_exponents=A_e[lp.edge_local_to_global], epsilon=eps[l2g],
+            mu_boundary=mu_b[lp.boundary_positions], n_probes=0 if probes is None else len(probes),
+        )
+        if probes is not None:
+            g2l = np.full(n, -1, dtype=np.int64)
+            g2l[l2g[: lp.n_own]] = np.arange(lp.n_own)
+            loc = g2l[probes]
+            pay["probe_mine"] = np.flatnonzero(loc >= 0)
+            pay["probe_local"] = loc[pay["probe_mine"]]
+        if screening is not None:
+            pay["screening"] = dict(sites=np.asarray(screening["sites"]), areas=np.asarray(screening["areas"]),
+                                    edge_centers=np.asarray(screening["edge_centers"])[lp.edge_local_to_global])
+        out.append(pay)
+    return out
+
+
+def _own_payload(mesh, world, rank, link_exponents, epsilon, terminal_info, mu_boundary, probe_points, screening,
+                 max_coarse):
+    """Legacy construction: every rank holds the global mesh and prepares only its own piece (the
+    global hierarchy is still built on every rank -- fine for small problems and tests)."""
+    pieces = prepare_payloads_for(mesh, world, [rank], link_exponents, epsilon, terminal_info=terminal_info,
+                                  mu_boundary=mu_boundary, probe_points=probe_points, screening=screening,
+                                  max_coarse=max_coarse)
+    return pieces[0]
+
+
 class DistributedTDGL:
-    def __init__(self, mesh, options, link_exponents, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
+    """One rank of a domain-decomposed run.
+
+    Three ways to construct (every rank of the job calls the constructor):
+
+    * ``root=None`` (default): every rank holds the global ``mesh`` and cuts its own piece
+      (small problems, tests);
+    * ``root=k``: only rank k needs ``mesh`` / ``link_exponents`` / ... (the others pass ``None``);
+      it runs `prepare_payloads` once and scatters the pieces over the bootstrap process group, so
+      the global mesh and the AMG set-up exist once per job, not once per rank;
+    * ``payload=...``: a piece prepared ahead of time (`prepare_payloads`)."""
+
+    def __init__(self, mesh, options, link_exponents=None, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
                  terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
-                 overlap="auto", screening=None):
+                 overlap="auto", screening=None, root=None, payload=None, max_coarse=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -58,16 +132,25 @@ class DistributedTDGL:
         self.mesh = mesh
         self.options = options
         options.validate()
-        em = mesh.edge_mesh
-        n = len(mesh.sites)
-        fixed = (
-            np.concatenate([np.asarray(t["site_indices"] if isinstance(t, dict) else t.site_indices)
-                            for t in terminal_info]).astype(np.int64)
-            if len(terminal_info) else np.array([], dtype=np.int64)
-        )
-        self.fixed_sites = fixed
-        self.part = rcb_partition(mesh.sites, self.world)
-        self.lp = lp = build_local_problem(mesh, self.part, self.rank, fixed_sites=fixed)
+        if payload is None:
+            if root is None:
+                payload = _own_payload(mesh, self.world, self.rank, link_exponents, epsilon, terminal_info,
+                                       mu_boundary, probe_points, screening, max_coarse)
+            else:
+                pieces = None
+                if self.rank == int(root):
+                    pieces = prepare_payloads(mesh, self.world, link_exponents, epsilon, terminal_info=terminal_info,
+                                              mu_boundary=mu_boundary, probe_points=probe_points,
+                                              screening=screening, max_coarse=max_coarse)
+                if self.world > 1:
+                    got = [None]
+                    dist.scatter_object_list(got, pieces, src=int(root))
+                    payload = got[0]
+                else:
+                    payload = pieces[0]
+        self.payload = payload
+        self.lp = lp = payload["lp"]
+        self.n_global, self.m_global = payload["n_global"], payload["m_global"]
         dev = self.rank if device_id is None else device_id
         self.ctx = ctx = TDGLContext(
             lp.mesh, fixed_sites=lp.fixed_sites, fix_psi=(options.terminal_psi is not None), u=u, gamma=gamma,
@@ -85,38 +168,31 @@ class DistributedTDGL:
                 ctx.comm_init_callbacks(self._halo_cb, self._allreduce_cb)
             else:
                 raise ValueError(f"unknown transport {transport!r}")
-        # the same global hierarchy on every rank (deterministic set-up), level 0 sliced
-        A_glob = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
-        # (level 0 is the distributed one, so the hierarchy needs at least one coarser level)
-        self.hierarchy = build_hierarchy(A_glob, max_coarse=min(600, max(8, n // 4)))
-        ctx.set_hierarchy_distributed(self.hierarchy, lp)
+        ctx.set_hierarchy_sliced(payload["level0"], payload["coarse"], lp)
+        self.hierarchy = ctx.hierarchy
         ctx.set_poisson_options(
             rtol=options.pcg_rtol, max_iter=options.pcg_max_iter, nu=options.amg_smoothing_sweeps,
             edge_currents_every_step=options.edge_currents_every_step,
         )
-        l2g = lp.local_to_global
-        ctx.set_link_exponents(np.asarray(link_exponents, dtype=float)[lp.edge_local_to_global])
-        ctx.set_epsilon((np.asarray(epsilon, dtype=float) * np.ones(n))[l2g])
-        self.set_mu_boundary(np.zeros(len(em.boundary_edge_indices)) if mu_boundary is None else mu_boundary)
+        ctx.set_link_exponents(payload["link_exponents"])
+        ctx.set_epsilon(payload["epsilon"])
+        ctx.set_mu_boundary(payload["mu_boundary"])
         ctx.set_controller(options.dt_init, options.dt_max, options.adaptive, options.adaptive_window,
                            options.max_solve_retries, options.adaptive_time_step_multiplier)
-        # screening: ``dict(sites[n, 2], areas[n] (scaled), edge_centers[m, 2])`` in GLOBAL numbering
-        self.screening = screening
-        if screening is not None:
+        # screening: global site arrays + this rank's edge centres
+        self.screening = payload.get("screening")
+        if self.screening is not None:
             ctx.set_screening_distributed(
-                screening["sites"], screening["areas"], l2g[: lp.n_own],
-                np.asarray(screening["edge_centers"])[lp.edge_local_to_global],
+                self.screening["sites"], self.screening["areas"], lp.local_to_global[: lp.n_own],
+                self.screening["edge_centers"],
                 max_iterations=options.max_iterations_per_step, tolerance=options.screening_tolerance,
                 step_size=options.screening_step_size, step_drag=options.screening_step_drag,
             )
         # probes: each rank reads the ones it owns
-        self.probe_points = None if probe_points is None else np.asarray(probe_points, dtype=np.int64)
-        if self.probe_points is not None:
-            g2l = np.full(n, -1, dtype=np.int64)
-            g2l[l2g[: lp.n_own]] = np.arange(lp.n_own)
-            loc = g2l[self.probe_points]
-            self._probe_mine = np.flatnonzero(loc >= 0)
-            ctx.set_probes(loc[self._probe_mine])
+        self.n_probes = payload["n_probes"]
+        if self.n_probes:
+            self._probe_mine = payload["probe_mine"]
+            ctx.set_probes(payload["probe_local"])
 
     # -- gloo transport (tests) -----------------------------------------------------------------
     def _halo_cb(self, send, send_off, recv, recv_off, ranks):
@@ -147,8 +223,13 @@ class DistributedTDGL:
         self.ctx.set_mu_boundary(np.asarray(mu_boundary_global, dtype=float)[self.lp.boundary_positions])
 
     def set_state(self, psi_global, mu_global):
+        """Global arrays (every rank passes the same ones), or scalars for a uniform state."""
         l2g = self.lp.local_to_global
-        self.ctx.set_state(np.asarray(psi_global)[l2g], np.asarray(mu_global, dtype=float)[l2g])
+        psi = np.full(len(l2g), psi_global, dtype=complex) if np.ndim(psi_global) == 0 else np.asarray(psi_global)[l2g]
+        mu = np.full(len(l2g), mu_global, dtype=float) if np.ndim(mu_global) == 0 else np.asarray(mu_global, dtype=float)[l2g]
+        if np.ndim(psi_global) == 0 and self.options.terminal_psi is not None and len(self.lp.fixed_sites):
+            psi[self.lp.fixed_sites] = self.options.terminal_psi  # solver.py:285-287
+        self.ctx.set_state(psi, mu)
 
     def begin_stage(self):
         self.ctx.begin_stage()
@@ -156,10 +237,10 @@ class DistributedTDGL:
     # -- stepping -----------------------------------------------------------------------------------
     def run(self, max_steps, end_time=np.inf):
         res = self.ctx.run(max_steps, end_time)
-        if self.probe_points is not None and self.world > 1:
+        if self.n_probes and self.world > 1:
             import torch
 
-            k, npb = len(res["dt"]), len(self.probe_points)
+            k, npb = len(res["dt"]), self.n_probes
             both = np.zeros((2, k, npb))
             if len(self._probe_mine):
                 both[0][:, self._probe_mine] = res["mu"]
@@ -175,7 +256,7 @@ class DistributedTDGL:
 
         lp = self.lp
         st = self.ctx.get_state()
-        n, m = len(self.mesh.sites), len(self.mesh.edge_mesh.edges)
+        n, m = self.n_global, self.m_global
         own = lp.local_to_global[: lp.n_own]
         sites = np.zeros((3, n))
         sites[0, own], sites[1, own], sites[2, own] = st["psi"].real[: lp.n_own], st["psi"].imag[: lp.n_own], st["mu"][: lp.n_own]

@@ -39,6 +39,15 @@ def poisson_matrix(edges, weights, n, iperm=None) -> sp.csr_matrix:
     return A
 
 
+class _HierarchyInfo:
+    """A rank's view of a decomposed hierarchy: the local levels plus the global sizes."""
+
+    def __init__(self, local, sizes=None, operator_complexity=None):
+        self.levels, self.coarse_pinv = local.levels, local.coarse_pinv
+        self.sizes = list(sizes) if sizes is not None else local.sizes
+        self.operator_complexity = operator_complexity if operator_complexity is not None else local.operator_complexity
+
+
 class TDGLContext:
     """Owns one ``tdgl_ctx`` (device buffers + stream) for a mesh."""
 
@@ -206,6 +215,18 @@ class TDGLContext:
         self._local_level0 = lv0
         self.set_hierarchy(hh, n_cols0=lp.n_loc)
         self.hierarchy = h
+
+    def set_hierarchy_sliced(self, level0: dict, coarse: dict, lp):
+        """Upload a hierarchy given as this rank's level-0 slice (`partition.local_hierarchy_level0`)
+        plus the replicated coarser levels (``dict(levels=[...], coarse_pinv=...)``): what
+        `distributed.prepare_payloads` ships to a rank."""
+        from .amg import Level
+
+        lv0 = Level(A=level0["A"], dinv=level0["dinv"], rho=level0["rho"], P=level0["P"], R=level0["R"])
+        hh = Hierarchy(levels=[lv0] + list(coarse["levels"]), coarse_pinv=coarse["coarse_pinv"])
+        self._local_level0 = lv0
+        self.set_hierarchy(hh, n_cols0=lp.n_loc)
+        self.hierarchy = _HierarchyInfo(hh, coarse.get("sizes"), coarse.get("operator_complexity"))
 
     def set_hierarchy(self, h: Hierarchy, n_cols0: int = 0):
         levels = (_lib.AmgLevel * len(h.levels))()

@@ -182,3 +182,57 @@ def test_distributed_step_matches_single_domain_oracle(world, case, tmp_path):
     assert res["psi_err"] < 1e-14  # pointwise update of identical inputs
     assert res["js_err"] < 1e-13
     assert res["mu_err"] < 1e-9  # PCG to 1e-12 vs LU, modulo the constant
+
+
+# ---------------------------------------------------------------- root-built pieces
+def _payload_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdgl_amd.distributed import prepare_payloads
+
+        pieces = None
+        if rank == 0:  # only the root ever sees the global mesh
+            mesh = synthetic_mesh(40, 25)
+            terms = [edge_terminal(mesh, "source", -20.0), edge_terminal(mesh, "drain", 20.0)]
+            pieces = prepare_payloads(mesh, world, uniform_field_A(mesh, 0.05), 1.0, terminal_info=terms,
+                                      probe_points=[mesh.closest_site((-5, 0)), mesh.closest_site((5, 0))])
+        got = [None]
+        dist.scatter_object_list(got, pieces, src=0)
+        pay = got[0]
+        lp = pay["lp"]
+        np.savez(os.path.join(out_dir, f"piece_{rank}.npz"), l2g=lp.local_to_global, n_own=lp.n_own,
+                 A_shape=pay["level0"]["A"].shape, eps=pay["epsilon"], links=pay["link_exponents"],
+                 edge_l2g=lp.edge_local_to_global, probe_mine=pay["probe_mine"], n_global=pay["n_global"],
+                 coarse_sizes=[lv.A.shape[0] for lv in pay["coarse"]["levels"]])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_root_builds_and_scatters_the_pieces(tmp_path):
+    """`DistributedTDGL(root=0)`'s set-up path without a GPU: rank 0 partitions, slices the hierarchy
+    and the inputs; the pieces arrive intact and equal what every rank would have cut itself."""
+    from tdgl_amd.distributed import prepare_payloads_for
+
+    world = 2
+    mp.spawn(_payload_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mesh = synthetic_mesh(40, 25)
+    terms = [edge_terminal(mesh, "source", -20.0), edge_terminal(mesh, "drain", 20.0)]
+    A = uniform_field_A(mesh, 0.05)
+    seen_probes = []
+    for r in range(world):
+        got = np.load(os.path.join(tmp_path, f"piece_{r}.npz"))
+        want = prepare_payloads_for(mesh, world, [r], A, 1.0, terminal_info=terms,
+                                    probe_points=[mesh.closest_site((-5, 0)), mesh.closest_site((5, 0))])[0]
+        assert np.array_equal(got["l2g"], want["lp"].local_to_global)
+        assert int(got["n_own"]) == want["lp"].n_own and int(got["n_global"]) == len(mesh.sites)
+        assert tuple(got["A_shape"]) == (want["lp"].n_own, want["lp"].n_loc)
+        assert np.array_equal(got["links"], A[got["edge_l2g"]])
+        assert np.array_equal(got["coarse_sizes"], [lv.A.shape[0] for lv in want["coarse"]["levels"]])
+        seen_probes += list(got["probe_mine"])
+    assert sorted(seen_probes) == [0, 1]  # every probe is read by exactly one rank
