@@ -221,6 +221,10 @@ def main():
                     help="keep the level-0 operators of the V-cycle in fp64 (default: fp32 storage inside the fp64 CG)")
     ap.add_argument("--no-fused-restriction", action="store_true",
                     help="restrict the level-0 residual with two kernels instead of the pre-multiplied operator")
+    ap.add_argument("--no-collapse", action="store_true",
+                    help="run the coarse AMG levels kernel by kernel instead of through the collapsed operators")
+    ap.add_argument("--tail-cycles", type=int, default=2,
+                    help="V-cycles folded into the explicit operators of the tail level (1 = the plain cycle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--force-distributed", action="store_true",
@@ -266,7 +270,7 @@ def main():
     popt = dict(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                 edge_currents_every_step=True, smoother=args.smoother, extrapolate=args.extrapolate,
                 nu_fine=args.nu_fine, fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
-                precond_fp32=not args.precond_fp64)
+                precond_fp32=not args.precond_fp64, collapse=not args.no_collapse, tail_cycles=args.tail_cycles)
 
     def run_workload(name, want_cpu_state):
         """Set up `name`, pre-roll + warm up, time K steps.  Returns a dict of measurements (rank 0
@@ -405,7 +409,7 @@ def main():
 
     main_line = line_for(main_run) if rank == 0 else None
     # the kernel that dominates the run time: the CG's fused direction update + A p (k_sell_axp), timed
-    # in the run on its first 256 launches; algorithmic bytes = K5 SpMV + the direction update's 24 n
+    # in the run on every 8th launch (up to 64 samples); algorithmic bytes = K5 SpMV + the direction update's 24 n
     roofline_pcg = None
     if rank == 0 and main_run.axp[0] > 0:
         ab = algorithmic_bytes(main_run.n_loc, main_run.m_loc)

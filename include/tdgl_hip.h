@@ -151,6 +151,32 @@ int tdgl_poisson_set_fused_restriction(tdgl_ctx *ctx, int64_t n_rows, int64_t n_
 int tdgl_poisson_set_fused_level(tdgl_ctx *ctx, int32_t level, const int32_t *ra_indptr, const int32_t *ra_indices,
                                  const double *ra_data, const int32_t *ap_indptr, const int32_t *ap_indices,
                                  const double *ap_data, const double *p_on_ap_data);
+/* Optional: the collapsed coarse chain.  Levels below level 0 move a few MB per kernel and are bound
+ * by kernel boundaries and dependent memory round trips; the host (tdgl_amd/amg.py:
+ * collapsed_operators) re-associates the SAME V-cycle into fewer, denser operators:
+ *   - tdgl_poisson_set_collapsed_level(level, M): M = R (I - A S) [n_coarse x n] (CSR) of an
+ *     intermediate level, S = the two-step pre-smoothing polynomial.  The next level's right-hand
+ *     side M b and the pre-smoothing x = S b then share one launch.  m_indptr == NULL: off.
+ *   - tdgl_poisson_set_collapsed_tail(t): everything from level t->level down.
+ *       mode 0: e = G b, G = dense [n, n] (the cycle of that level formed explicitly, or the exact
+ *               pseudo-inverse of its operator);
+ *       mode 1: y = G b (G dense [g_rows, n]), e = W b + V y (W CSR [n, n], V dense [n, g_rows]).
+ *     nu / smoother / cheb_lo are the smoother settings the operators were built for; the library
+ *     falls back to the plain kernel sequence while tdgl_poisson_options differ.  t == NULL: off.
+ * Replaced hierarchies drop both. */
+typedef struct {
+    int32_t level;
+    int32_t mode;
+    const double *G;
+    int64_t g_rows;                /* mode 1 */
+    const int32_t *W_indptr;  const int32_t *W_indices;  const double *W_data;   /* mode 1 */
+    const double *V;               /* mode 1: dense row-major [n, g_rows] */
+    int32_t nu, smoother;
+    double cheb_lo;
+} tdgl_collapsed_tail;
+int tdgl_poisson_set_collapsed_level(tdgl_ctx *ctx, int32_t level, const int32_t *m_indptr, const int32_t *m_indices,
+                                     const double *m_data);
+int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *tail);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);
@@ -355,7 +381,7 @@ int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms
 int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on);
 int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
 /* The same for the kernel that dominates the run time, the CG's fused direction update + A p
- * (k_sell_axp): the first 256 launches after tdgl_profile_enable are timed (single GPU). */
+ * (k_sell_axp): every 8th launch after tdgl_profile_enable is timed, up to 64 samples (single GPU). */
 int tdgl_profile_read_pcg(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus

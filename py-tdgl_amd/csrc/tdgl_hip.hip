@@ -881,7 +881,8 @@ extern "C" int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on) {
     ctx->prof_ms = 0.0;
     ctx->prof2_launches = 0;
     ctx->prof2_ms = 0.0;
-    ctx->prof2_budget = on ? 256 : 0;
+    ctx->prof2_budget = on ? 64 : 0;
+    ctx->prof2_seen = 0;
     return TDGL_OK;
 }
 

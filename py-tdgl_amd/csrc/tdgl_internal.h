@@ -108,6 +108,8 @@ struct AmgLevel {
     Csr AP;                          // A P   [n x n_coarse]
     DevBuf<double> APp;              // P on the pattern of A P
     DevBuf<float> APp32;
+    // collapsed coarse chain (tdgl_poisson_set_collapsed_level): M = R (I - A S) [n_coarse x n]
+    Csr M;
 };
 
 // scalars of the PCG recurrence, resident on the device
@@ -218,6 +220,17 @@ struct tdgl_ctx {
     int64_t f32_fallbacks = 0;            // solves that had to be finished with the fp64 operators
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
+    // collapsed coarse chain (tdgl_poisson_set_collapsed_tail): everything from level `tail_level`
+    // down as explicit operators, built for the smoother settings (tail_nu, tail_smoother, tail_cheb_lo)
+    int tail_level = -1;                  // -1: off
+    int tail_mode = 0;                    // 0: e = B b (dense [n_t, n_t]);  1: y = G b, e = W b + V y
+    int64_t tail_g_rows = 0;              // rows of G = columns of V
+    tdgl::DevBuf<double> tailG, tailV;    // dense row-major (mode 0: tailG holds B)
+    tdgl::DevBuf<float> tailG32, tailV32;
+    tdgl::Csr tailW;
+    tdgl::DevBuf<double> tail_y;          // G b
+    int tail_nu = 0, tail_smoother = 0;
+    double tail_cheb_lo = 0.0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
     tdgl::DevBuf<double> pcg_p2;          // second direction buffer (fused direction update, k_sell_axp)
     tdgl::DevBuf<double> part_pair[2];    // 2 x NB partials each: [r.z | ||r||^2], ping-pong
@@ -275,7 +288,7 @@ struct tdgl_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
     // the same for the kernel that dominates the run time (the CG's fused A p), sampled: only the
     // first prof2_budget launches after tdgl_profile_enable are bracketed by events
-    int64_t prof2_launches = 0, prof2_budget = 0;
+    int64_t prof2_launches = 0, prof2_budget = 0, prof2_seen = 0;
     double prof2_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_pending;
 };

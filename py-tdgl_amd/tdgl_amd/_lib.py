@@ -109,6 +109,22 @@ class PoissonOptions(C.Structure):
     ]
 
 
+class CollapsedTail(C.Structure):
+    _fields_ = [
+        ("level", C.c_int32),
+        ("mode", C.c_int32),
+        ("G", c_f64p),
+        ("g_rows", C.c_int64),
+        ("W_indptr", c_i32p),
+        ("W_indices", c_i32p),
+        ("W_data", c_f64p),
+        ("V", c_f64p),
+        ("nu", C.c_int32),
+        ("smoother", C.c_int32),
+        ("cheb_lo", C.c_double),
+    ]
+
+
 class ScreeningOptions(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_int32),
@@ -136,6 +152,8 @@ SIGNATURES = {
     "tdgl_poisson_set_fused_restriction": (
         C.c_int, [_CTX, C.c_int64, C.c_int64, c_i32p, c_i32p, c_f64p, C.c_double]
     ),
+    "tdgl_poisson_set_collapsed_level": (C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p]),
+    "tdgl_poisson_set_collapsed_tail": (C.c_int, [_CTX, C.POINTER(CollapsedTail)]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
     "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),

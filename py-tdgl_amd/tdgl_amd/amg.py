@@ -331,3 +331,155 @@ def pcg_host(A, b, h: Hierarchy, x0=None, rtol=1e-10, maxiter=200, nu=2, smoothe
         p = z + (rz_new / rz) * p
         rz = rz_new
     return x - x.mean(), it, res
+
+
+# ---------------------------------------------------------------------------------------
+# Collapsed coarse levels.  The levels below level 0 move a few MB per kernel and are bound by
+# kernel boundaries and dependent memory round trips, not by bandwidth.
+# Everything here is the SAME V-cycle re-associated into fewer, denser operators, built once on
+# the host (the counterpart of the reference's one-off LU factorisation, operators.py:305-308):
+#
+#   * an intermediate level k:  x_k = S_k b_k is the fused two-step pre-smoothing (unchanged), but
+#     the next right-hand side is b_{k+1} = M_k b_k with M_k = R_k (I - A_k S_k) explicit, so the
+#     restriction no longer waits for x_k: one launch computes both;
+#   * the tail: the first level t with at most `tail_rows` rows.  The whole cycle below it is the
+#     dense matrix B_{t+1} (pseudo-inverse of the coarsest operator, or an explicitly formed small
+#     cycle).  Then  e_{t+1} = G b_t,  G = B_{t+1} M_t  (dense [n_{t+1}, n_t]), and the post-smoothed
+#     result is  e_t = W b_t + V e_{t+1},  W = T_x S_t + T_b,  V = T_x P_t  (sparse), where
+#     y = T_x x' + T_b b is the two-step post-smoothing as one operator: two launches for
+#     everything from level t down.  If level t itself is small (<= dense_rows) its cycle is formed
+#     densely, B_t, and applied in one launch.
+def smoothing_operators(A, dinv, rho, nu=2, smoother="chebyshev", cheb_lo=0.1):
+    """``(S, T_x, T_b)``: pre-smoothing from a zero guess ``x = S b`` and post-smoothing
+    ``y = T_x x' + T_b b`` of `vcycle_host` as explicit sparse operators."""
+    c1, c2 = smoother_coefficients(rho, nu, smoother, cheb_lo)
+    n = A.shape[0]
+    D = sp.diags(dinv)
+    DA = (D @ A).tocsr()
+    eye = sp.identity(n, format="csr")
+    # pre: d = c2[0] D b, x = d; then d = c1[k] d + c2[k] D (b - A x), x += d   (as operators on b)
+    Dop, Xop = c2[0] * D, c2[0] * D
+    for k in range(1, nu):
+        Dop = c1[k] * Dop + c2[k] * (D - DA @ Xop)
+        Xop = Xop + Dop
+    S = sp.csr_matrix(Xop)
+    # post: the polynomial restarts from x' with d = 0 (c1[0] = 0)
+    Dx, Db = sp.csr_matrix((n, n)), sp.csr_matrix((n, n))
+    Xx, Xb = eye, sp.csr_matrix((n, n))
+    for k in range(nu):
+        Dx = c1[k] * Dx - c2[k] * (DA @ Xx)
+        Db = c1[k] * Db + c2[k] * (D - DA @ Xb)
+        Xx, Xb = Xx + Dx, Xb + Db
+    Tx, Tb = sp.csr_matrix(Xx), sp.csr_matrix(Xb)
+    for M in (S, Tx, Tb):
+        M.sort_indices()
+    return S, Tx, Tb
+
+
+def dense_cycle(h: Hierarchy, lvl: int, nu=2, smoother="chebyshev", cheb_lo=0.1) -> np.ndarray:
+    """The V-cycle from level ``lvl`` down as a dense matrix (small levels only)."""
+    if lvl == len(h.levels) - 1:
+        return np.asarray(h.coarse_pinv)
+    lv = h.levels[lvl]
+    S, Tx, Tb = smoothing_operators(lv.A, lv.dinv, lv.rho, nu, smoother, cheb_lo)
+    S, Tx, Tb = S.toarray(), Tx.toarray(), Tb.toarray()
+    A, P, R = lv.A.toarray(), lv.P.toarray(), lv.R.toarray()
+    Bc = dense_cycle(h, lvl + 1, nu, smoother, cheb_lo)
+    n = A.shape[0]
+    return Tx @ (S + P @ (Bc @ (R @ (np.eye(n) - A @ S)))) + Tb
+
+
+def exact_pinv(A) -> np.ndarray:
+    """Dense pseudo-inverse of a symmetric positive semi-definite operator whose null space is the
+    constant vector (the same construction as `Hierarchy.coarse_pinv`)."""
+    M = A.toarray() if sp.issparse(A) else np.asarray(A)
+    n = M.shape[0]
+    J = np.full((n, n), 1.0 / n)
+    return np.linalg.inv(M + J) - J
+
+
+def collapsed_operators(h: Hierarchy, nu=2, smoother="chebyshev", cheb_lo=0.1, tail_rows=8192, dense_rows=1536,
+                        tail_cycles=2):
+    """Plan of the collapsed coarse chain: ``dict(mid={k: M_k}, tail=t, mode="dense"|"gwv", ...)`` or
+    ``None`` when the hierarchy has no intermediate level to collapse.
+
+    ``tail_cycles``: how accurately the tail level is solved.  Applying explicit operators costs the
+    same two launches whatever they contain, so the tail can afford more than one V-cycle:
+    1 = the plain cycle (bit-for-bit the re-association of `vcycle_host`); 2 (default) = two cycles,
+    ``B' = B (2 I - A B)``, folded into operators of the same shape (dense mode: the exact
+    pseudo-inverse).  With the 10-18x coarsening per level used here the plain V-cycle's inexact
+    coarse solves cost ~20 % more PCG iterations than a near-exact tail."""
+    L = len(h.levels)
+    if L < 3:
+        return None
+    sizes = h.sizes
+    t = None
+    for k in range(1, L - 1):
+        if sizes[k] <= dense_rows or (sizes[k] <= tail_rows and sizes[k + 1] <= dense_rows):
+            t = k
+            break
+    if t is None:
+        return None
+    plan = dict(tail=t, mid={}, coef=(nu, smoother, cheb_lo), tail_cycles=int(tail_cycles))
+    for k in range(1, t):
+        lv = h.levels[k]
+        S, _, _ = smoothing_operators(lv.A, lv.dinv, lv.rho, nu, smoother, cheb_lo)
+        M = (lv.R @ (sp.identity(sizes[k], format="csr") - lv.A @ S)).tocsr()
+        M.sort_indices()
+        plan["mid"][k] = M
+    lv = h.levels[t]
+    if sizes[t] <= dense_rows:
+        plan["mode"] = "dense"
+        plan["B"] = np.ascontiguousarray(
+            dense_cycle(h, t, nu, smoother, cheb_lo) if tail_cycles <= 1 else exact_pinv(lv.A))
+        return plan
+    S, Tx, Tb = smoothing_operators(lv.A, lv.dinv, lv.rho, nu, smoother, cheb_lo)
+    M = (lv.R @ (sp.identity(sizes[t], format="csr") - lv.A @ S)).tocsr()
+    Bc = dense_cycle(h, t + 1, nu, smoother, cheb_lo)
+    plan["mode"] = "gwv"
+    G = Bc @ M.toarray()                                     # [n_{t+1}, n_t]
+    W = (Tx @ S + Tb).tocsr()
+    V = (Tx @ lv.P).toarray()                                # [n_t, n_{t+1}]
+    if tail_cycles >= 2:
+        # B = W + V G;  B' = 2 B - B A B = W' + [V1 | -V] [G ; H]  with
+        #   W' = 2 W - W A W,  K = G A V,  H = G A W,  V1 = 2 V - W A V - V K
+        A = lv.A.tocsr()
+        AW = (A @ W).tocsr()
+        H = np.asarray(G @ AW.toarray()) if AW.shape[0] <= 2048 else np.asarray((AW.T @ G.T).T)
+        AV = A @ V
+        K = G @ AV
+        V1 = 2.0 * V - W @ AV - V @ K
+        W = (2.0 * W - W @ AW).tocsr()
+        G = np.vstack([G, H])
+        V = np.hstack([V1, -V])
+    W.sort_indices()
+    plan["G"] = np.ascontiguousarray(G)
+    plan["W"], plan["V"] = W, np.ascontiguousarray(V)
+    return plan
+
+
+def vcycle_collapsed_host(h: Hierarchy, plan, b: np.ndarray, nu=2, smoother="chebyshev", cheb_lo=0.1,
+                          nu_fine=0) -> np.ndarray:
+    """`vcycle_host` evaluated through the collapsed operators (test helper: must agree with the
+    plain cycle to round-off)."""
+    def level(k, bk):
+        lv = h.levels[k]
+        if k == plan["tail"]:
+            if plan["mode"] == "dense":
+                return plan["B"] @ bk
+            return plan["W"] @ bk + plan["V"] @ (plan["G"] @ bk)
+        n_here = nu_fine if (k == 0 and nu_fine > 0) else nu
+        c1, c2 = smoother_coefficients(lv.rho, n_here, smoother, cheb_lo)
+        d = c2[0] * lv.dinv * bk
+        x = d.copy()
+        for s in range(1, n_here):
+            d = c1[s] * d + c2[s] * lv.dinv * (bk - lv.A @ x)
+            x = x + d
+        bc = plan["mid"][k] @ bk if k in plan["mid"] else lv.R @ (bk - lv.A @ x)
+        x = x + lv.P @ level(k + 1, bc)
+        for s in range(n_here):
+            d = c1[s] * d + c2[s] * lv.dinv * (bk - lv.A @ x)
+            x = x + d
+        return x
+
+    return level(0, b)

@@ -255,8 +255,10 @@ class TDGLContext:
         pinv = f64(h.coarse_pinv)
         self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
         self.hierarchy = h
+        self._hier_epoch = getattr(self, "_hier_epoch", 0) + 1
         self._refresh_fused_restriction()
         self._set_fused_levels(h)
+        self._refresh_collapsed()
 
     def _set_fused_levels(self, h, on=True):
         """Pre-multiplied transfer operators of the coarse levels (one launch instead of two on
@@ -297,9 +299,50 @@ class TDGLContext:
         self._chk(self._lib.tdgl_poisson_set_fused_restriction(
             self._ctx, M.shape[0], M.shape[1], p_i32(ip), p_i32(ix), p_f64(dx), float(c)))
 
+    def _refresh_collapsed(self):
+        """(Re)build the collapsed coarse chain for the smoother settings in use
+        (`amg.collapsed_operators`; `tdgl_poisson_set_collapsed_level` / `_tail`)."""
+        h, o = getattr(self, "hierarchy", None), getattr(self, "poisson_options", None)
+        if h is None or o is None or len(h.levels) < 3:
+            return
+        lib, ctx = self._lib, self._ctx
+        key = (getattr(self, "_hier_epoch", 0), o["nu"], o["smoother"], o["cheb_lo"], o.get("collapse", True),
+               o.get("tail_cycles", 2))
+        if getattr(self, "_collapsed_key", None) == key:
+            return
+        self._collapsed_key = key
+        from .amg import collapsed_operators
+
+        name = "jacobi" if o["smoother"] == 0 else "chebyshev"
+        plan = collapsed_operators(h, o["nu"], name, o["cheb_lo"], tail_cycles=o.get("tail_cycles", 2)) \
+            if (o.get("collapse", True) and o["nu"] == 2) else None
+        self.collapsed_plan = plan
+        for k in range(1, len(h.levels) - 1):
+            M = None if plan is None else plan["mid"].get(k)
+            if M is None:
+                self._chk(lib.tdgl_poisson_set_collapsed_level(ctx, k, None, None, None))
+            else:
+                a = (i32(M.indptr), i32(M.indices), f64(M.data))
+                self._chk(lib.tdgl_poisson_set_collapsed_level(ctx, k, p_i32(a[0]), p_i32(a[1]), p_f64(a[2])))
+        if plan is None:
+            self._chk(lib.tdgl_poisson_set_collapsed_tail(ctx, None))
+            return
+        t = _lib.CollapsedTail()
+        t.level, t.nu, t.smoother, t.cheb_lo = plan["tail"], int(o["nu"]), int(o["smoother"]), float(o["cheb_lo"])
+        if plan["mode"] == "dense":
+            keep = (f64(plan["B"]),)
+            t.mode, t.G, t.g_rows = 0, p_f64(keep[0]), keep[0].shape[0]
+        else:
+            W = plan["W"]
+            keep = (f64(plan["G"]), i32(W.indptr), i32(W.indices), f64(W.data), f64(plan["V"]))
+            t.mode, t.G, t.g_rows = 1, p_f64(keep[0]), keep[0].shape[0]
+            t.W_indptr, t.W_indices, t.W_data, t.V = p_i32(keep[1]), p_i32(keep[2]), p_f64(keep[3]), p_f64(keep[4])
+        self._chk(lib.tdgl_poisson_set_collapsed_tail(ctx, C.byref(t)))
+
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
-                            extrapolate=2, nu_fine=1, fused_restriction=True, precond_fp32=True):
+                            extrapolate=2, nu_fine=1, fused_restriction=True, precond_fp32=True,
+                            collapse=True, tail_cycles=2):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
@@ -307,9 +350,11 @@ class TDGLContext:
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
                                     fused_restriction=bool(fused_restriction), precond_fp32=bool(precond_fp32),
-                                    edge_currents_every_step=bool(edge_currents_every_step))
+                                    edge_currents_every_step=bool(edge_currents_every_step),
+                                    collapse=bool(collapse), tail_cycles=int(tail_cycles))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
         self._refresh_fused_restriction()
+        self._refresh_collapsed()
 
     # -- inputs ---------------------------------------------------------------------------
     def set_link_exponents(self, A):

@@ -206,7 +206,8 @@ def test_vcycle_with_fused_coarse_levels_matches_host_restatement():
     r = np.random.default_rng(5).normal(size=ctx.n)
     r -= r.mean()
     for smoother, nu, nu_fine in (("chebyshev", 2, 1), ("chebyshev", 3, 2), ("jacobi", 1, 1)):
-        ctx.set_poisson_options(rtol=1e-12, nu=nu, smoother=smoother, nu_fine=nu_fine)
+        # (tail_cycles=1: the collapsed coarse chain is then the plain cycle re-associated)
+        ctx.set_poisson_options(rtol=1e-12, nu=nu, smoother=smoother, nu_fine=nu_fine, tail_cycles=1)
         want = np.empty(ctx.n)
         want[ctx.perm] = vcycle_host(h, r[ctx.perm], nu=nu, smoother=smoother, nu_fine=nu_fine)
         got = ctx.vcycle(r)
@@ -221,6 +222,54 @@ def test_vcycle_with_fused_coarse_levels_matches_host_restatement():
     ctx.set_poisson_options(rtol=1e-12)
     mu, iters, relres = ctx.poisson_solve(rhs)
     assert relres < 1e-12 and iters < 40
+    ctx.close()
+
+
+@pytest.mark.parametrize("side, max_coarse, mode, n_mid", [(150, 40, "gwv", 0), (300, 40, "dense", 1)])
+def test_collapsed_coarse_chain_matches_host_restatement(side, max_coarse, mode, n_mid):
+    """The collapsed coarse chain (explicit M = R (I - A S) on intermediate levels; the tail level as
+    dense G / sparse W / dense V, or one dense matrix): with tail_cycles = 1 it is the plain V-cycle
+    re-associated (== vcycle_host and == the library's own plain kernel sequence); with the default
+    two tail cycles it is the host restatement through the same operators; fp32 storage of the
+    operators perturbs it by ~1e-7 only; and the solve needs fewer iterations."""
+    from tdgl_amd.amg import vcycle_collapsed_host, vcycle_host
+    from tdgl_amd.hipcore import TDGLContext
+
+    mesh = synthetic_mesh(side)
+    ctx = TDGLContext(mesh)
+    h = ctx.build_poisson(rtol=1e-12, max_coarse=max_coarse)
+    plan = ctx.collapsed_plan
+    assert plan is not None and plan["mode"] == mode and len(plan["mid"]) == n_mid, (h.sizes, plan["tail"])
+    r = np.random.default_rng(5).normal(size=ctx.n)
+    r -= r.mean()
+
+    def host(fn, *a):
+        out = np.empty(ctx.n)
+        out[ctx.perm] = fn(*a, r[ctx.perm], nu=2, smoother="chebyshev", nu_fine=1)
+        return out
+
+    ctx.set_poisson_options(rtol=1e-12, collapse=False)
+    plain = ctx.vcycle(r)
+    ctx.set_poisson_options(rtol=1e-12, tail_cycles=1)
+    got1 = ctx.vcycle(r)
+    assert max_abs(got1, host(vcycle_host, h)) < 1e-12 * np.abs(plain).max()
+    assert max_abs(got1, plain) < 1e-12 * np.abs(plain).max()
+    ctx.set_poisson_options(rtol=1e-12)  # default: two cycles on the tail
+    assert ctx.collapsed_plan["tail_cycles"] == 2
+    got2 = ctx.vcycle(r)
+    assert max_abs(got2, host(vcycle_collapsed_host, h, ctx.collapsed_plan)) < 1e-12 * np.abs(plain).max()
+    assert max_abs(got2, plain) > 1e-3 * np.abs(plain).max()  # a different (better) preconditioner
+    # the solves built on them: same solution, fewer iterations with the near-exact tail
+    rhs = np.random.default_rng(6).normal(size=ctx.n)
+    rhs -= (rhs * mesh.areas).sum() / mesh.areas.sum()
+    mu2, it2, rel2 = ctx.poisson_solve(rhs)
+    ctx.set_poisson_options(rtol=1e-12, collapse=False)
+    mu0, it0, rel0 = ctx.poisson_solve(rhs)
+    ctx.set_poisson_options(rtol=1e-12, precond_fp32=False)
+    mu64, it64, rel64 = ctx.poisson_solve(rhs)
+    assert rel2 < 1e-12 and rel0 < 1e-12 and rel64 < 1e-12 and it2 <= it0 and abs(it64 - it2) <= 1
+    scale = np.abs(mu0).max()
+    assert max_abs(mu2, mu0) < 1e-9 * scale and max_abs(mu64, mu0) < 1e-9 * scale
     ctx.close()
 
 

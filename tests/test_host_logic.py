@@ -369,3 +369,65 @@ def test_controller_mean_reproduces_numpy_summation_order():
             arr = np.ascontiguousarray(v, dtype=np.float64)
             got = lib.tdgl_host_mean_tail(arr.ctypes.data_as(C.POINTER(C.c_double)), len(arr), window)
             assert got == want, (size, window, got, want)
+
+
+def test_collapsed_coarse_operators_are_the_same_cycle():
+    """amg.collapsed_operators: intermediate-level M = R (I - A S), the tail as dense G / sparse W /
+    dense V (or one dense matrix).  With one tail cycle the chain is the plain V-cycle re-associated;
+    with two it is B (2 I - A B) on the tail level, a better preconditioner (fewer PCG iterations)."""
+    from tdgl_amd.amg import (build_hierarchy, collapsed_operators, pcg_host, smoothing_operators,
+                              vcycle_collapsed_host, vcycle_host)
+    from tdgl_amd.hipcore import poisson_matrix
+
+    mesh = synthetic_mesh(120)
+    em = mesh.edge_mesh
+    A = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, len(mesh.sites))
+    h = build_hierarchy(A, max_coarse=30)
+    assert len(h.levels) >= 4
+    rng = np.random.default_rng(0)
+    b = rng.normal(size=A.shape[0])
+    b -= b.mean()
+    z0 = vcycle_host(h, b, nu=2, nu_fine=1)
+    for kw in (dict(), dict(tail_rows=200, dense_rows=200), dict(tail_rows=200, dense_rows=20)):
+        plan = collapsed_operators(h, tail_cycles=1, **kw)
+        assert plan is not None
+        z1 = vcycle_collapsed_host(h, plan, b, nu=2, nu_fine=1)
+        assert np.abs(z1 - z0).max() < 1e-13 * np.abs(z0).max(), (kw, plan["mode"], plan["tail"])
+    modes = {collapsed_operators(h, tail_cycles=1, **kw)["mode"]
+             for kw in (dict(tail_rows=200, dense_rows=200), dict(tail_rows=200, dense_rows=20))}
+    assert modes == {"dense", "gwv"}
+    # the explicit smoothing operators restate the recurrences of vcycle_host
+    lv = h.levels[1]
+    S, Tx, Tb = smoothing_operators(lv.A, lv.dinv, lv.rho)
+    from tdgl_amd.amg import smoother_coefficients
+
+    c1, c2 = smoother_coefficients(lv.rho, 2)
+    bb = rng.normal(size=lv.A.shape[0])
+    d = c2[0] * lv.dinv * bb
+    x = d + (c1[1] * d + c2[1] * lv.dinv * (bb - lv.A @ d))
+    assert np.abs(S @ bb - x).max() < 1e-13 * np.abs(x).max()
+    xp = rng.normal(size=lv.A.shape[0])
+    y, dd = xp.copy(), 0.0
+    for k in range(2):
+        dd = c1[k] * dd + c2[k] * lv.dinv * (bb - lv.A @ y)
+        y = y + dd
+    assert np.abs(Tx @ xp + Tb @ bb - y).max() < 1e-13 * np.abs(y).max()
+    # two tail cycles: symmetric, and a better preconditioner
+    plan2 = collapsed_operators(h, tail_cycles=2, tail_rows=200, dense_rows=20)
+    assert plan2["mode"] == "gwv"
+    Bt = plan2["W"].toarray() + plan2["V"] @ plan2["G"]
+    assert np.abs(Bt - Bt.T).max() < 1e-10 * np.abs(Bt).max()
+
+    def iterations(plan):
+        import tdgl_amd.amg as amg
+
+        orig = amg.vcycle_host
+        try:
+            amg.vcycle_host = lambda hh, r, nu, smoother, nu_fine=0: vcycle_collapsed_host(hh, plan, r, nu, smoother,
+                                                                                           nu_fine=nu_fine)
+            return pcg_host(A, b, h, rtol=1e-10)[1]
+        finally:
+            amg.vcycle_host = orig
+
+    it1, it2 = iterations(collapsed_operators(h, tail_cycles=1)), iterations(collapsed_operators(h, tail_cycles=2))
+    assert it2 <= it1
