@@ -215,7 +215,10 @@ def main():
     ap.add_argument("--smoother", default="chebyshev", choices=["chebyshev", "jacobi"])
     ap.add_argument("--nu", type=int, default=2, help="smoother degree on the coarse levels")
     ap.add_argument("--nu-fine", type=int, default=1, help="smoother degree on level 0")
-    ap.add_argument("--extrapolate", type=int, default=2, help="initial-guess extrapolation order (0, 1, 2)")
+    ap.add_argument("--extrapolate", type=int, default=3,
+                    help="initial guess of the mu solve: 0 previous, 1/2 linear/quadratic extrapolation in time, "
+                         "3 projection onto the last --guess-window solutions")
+    ap.add_argument("--guess-window", type=int, default=6)
     ap.add_argument("--cheb-lo", type=float, default=0.1, help="Chebyshev smoothing interval [cheb_lo * rho, rho]")
     ap.add_argument("--precond-fp64", action="store_true",
                     help="keep the level-0 operators of the V-cycle in fp64 (default: fp32 storage inside the fp64 CG)")
@@ -270,7 +273,8 @@ def main():
     popt = dict(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                 edge_currents_every_step=True, smoother=args.smoother, extrapolate=args.extrapolate,
                 nu_fine=args.nu_fine, fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
-                precond_fp32=not args.precond_fp64, collapse=not args.no_collapse, tail_cycles=args.tail_cycles)
+                precond_fp32=not args.precond_fp64, collapse=not args.no_collapse, tail_cycles=args.tail_cycles,
+                guess_window=args.guess_window)
 
     def run_workload(name, want_cpu_state):
         """Set up `name`, pre-roll + warm up, time K steps.  Returns a dict of measurements (rank 0
@@ -343,7 +347,7 @@ def main():
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), axp=(axp_launches, axp_ms), comm=comm, sizes=list(h.sizes), start_state=start_state,
-            stats=ctx.poisson_stats(), overlap=ctx.comm_overlap() if use_dd else None,
+            stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats()), overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
                        pcg_iters=np.concatenate([t["pcg_iters"] for t in trace]).tolist()),

@@ -104,7 +104,10 @@ typedef struct {
     int32_t smoother;     /* 0 = damped Jacobi, 1 = Chebyshev in D^-1 A                */
     double cheb_lo;       /* Chebyshev interval [cheb_lo * rho, rho]                   */
     int32_t extrapolate;  /* initial guess: 0 = mu^n, 1 = linear, 2 = quadratic extrapolation
-                             in time through the last two / three solutions              */
+                             in time through the last two / three solutions, 3 (default) = the
+                             A-norm projection of the solution onto the span of the last
+                             guess_window solutions (the matrix is the same every step):
+                             ~40x smaller initial residual than the quadratic extrapolation  */
     int32_t nu_fine;      /* smoother degree on level 0 (0 = nu).  Default 1 with nu = 2:
                              halves the level-0 passes per cycle for ~5 % more iterations  */
     int32_t precond_fp32; /* 1 (default): the operators of the V-cycle (level 0: fused restriction,
@@ -115,6 +118,7 @@ typedef struct {
                              data only, so the solution meets the same rtol.  Active with
                              nu_fine = 1 and a fused restriction (z is kept in fp64 in
                              one-process-per-GPU mode, where its ghosts are exchanged).  */
+    int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..8 (0 = 6)   */
 } tdgl_poisson_options;
 
 /* ------------------------------------------------------------------ lifetime */
@@ -180,6 +184,13 @@ int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *ta
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);
+
+/* Quality of the last solve's initial guess: number of basis vectors it was projected on
+ * (extrapolate = 3; 0 = none) and ||b - A x0|| / ||b||. */
+int tdgl_get_guess_stats(tdgl_ctx *ctx, int32_t *vectors, double *initial_relres);
+/* Host-only: c = pinv(G) rhs for the k x k Gram matrix of the projection guess (eigen-decomposition,
+ * directions below 1e-13 of the largest eigenvalue dropped).  No device work. */
+int tdgl_host_solve_gram(int32_t k, const double *G_rowmajor, const double *rhs, double *c);
 
 /* ------------------------------------------------------------------ one process per GPU
  * The reference is single-process.  Here the mesh is cut into `world` pieces (host layer:

@@ -453,7 +453,8 @@ static void publish_status(tdgl_ctx *ctx) {
     const bool psi = ctx->psi_status_pending;
     hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->d_status.p, ctx->scal.p,
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
-                       psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks);
+                       psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
+                       ctx->d_gdot.n ? ctx->d_gdot.p : (const double *)nullptr);
     ctx->psi_status_pending = false;
 }
 
@@ -648,6 +649,8 @@ extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu
     ctx->lap_valid = false;
     ctx->currents_valid = false;
     ctx->prev_dt = ctx->prev_dt2 = 0.0;  // no mu history: the next solve starts from mu itself
+    ctx->g_count = 0;                     // (nor a projection basis)
+    ctx->g_diag_pending = false;
     return TDGL_OK;
 }
 

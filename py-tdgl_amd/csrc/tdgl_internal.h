@@ -117,14 +117,19 @@ struct AmgLevel {
 // rtol^2 ||b||^2 -- kept on the device so that the iteration kernels take no per-iteration
 // arguments and a pair of iterations can be replayed as a hipGraph)
 // (S_CG_*: r.z and alpha of the previous iteration for the single-reduction CG, ping-pong by parity)
-enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_CG_RZ0, S_CG_RZ1, S_CG_ALPHA0, S_CG_ALPHA1, S_COUNT = 12 };
+// (S_RR0: ||r_0||^2 of the current solve, recorded by the first update: the quality of the initial guess)
+enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_CG_RZ0, S_CG_RZ1, S_CG_ALPHA0, S_CG_ALPHA1, S_RR0, S_COUNT = 12 };
 
 // what a step reports back to the host at its synchronisation point
+constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels.inc: GK)
+
 struct StepStatus {
     int32_t fail_flag;          // psi update: discriminant < 0 or non-finite somewhere
     int32_t pad;
     unsigned long long dmax_bits[8];  // max | |psi'|^2 - |psi|^2 | as ordered uint64 bits, 8 slots
     double scal[S_COUNT];
+    // projection guess: x_j . b (j < GUESS_MAX), b . b, x_new . b_new of the previous solve
+    double gdot[GUESS_MAX + 2];
 };
 
 }  // namespace tdgl
@@ -238,7 +243,20 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
     tdgl::DevBuf<double> mu_prev, mu_prev2;  // mu^{n-1}, mu^{n-2} for the extrapolated initial guess
     double prev_dt = 0.0, prev_dt2 = 0.0;    // dt of the steps that produced mu / mu_prev (0: no history)
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 2, 1, 1};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 1, 6};
+    // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
+    // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
+    // step's status block
+    tdgl::DevBuf<double> g_x[tdgl::GUESS_MAX];
+    int g_slot[tdgl::GUESS_MAX] = {0};
+    int g_count = 0;
+    bool g_diag_pending = false;
+    double g_G[tdgl::GUESS_MAX][tdgl::GUESS_MAX] = {{0}};
+    double g_rhs[tdgl::GUESS_MAX] = {0};
+    tdgl::DevBuf<double> part_gdot;       // (GUESS_MAX + 2) x NB partials: [x_j . b | b . b | x_new . b_new]
+    tdgl::DevBuf<double> d_gdot;          // their sums
+    int32_t last_guess_vectors = 0;       // basis size the last guess was formed from
+    double last_guess_relres = 0.0;
     int32_t last_pcg_iters = 0;
     double last_relres = 0.0;
 

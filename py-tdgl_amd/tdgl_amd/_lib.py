@@ -106,6 +106,7 @@ class PoissonOptions(C.Structure):
         ("extrapolate", C.c_int32),
         ("nu_fine", C.c_int32),
         ("precond_fp32", C.c_int32),
+        ("guess_window", C.c_int32),
     ]
 
 
@@ -146,6 +147,8 @@ SIGNATURES = {
     "tdgl_poisson_set_hierarchy": (C.c_int, [_CTX, C.POINTER(AmgLevel), C.c_int32, c_f64p]),
     "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
     "tdgl_get_poisson_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64)]),
+    "tdgl_get_guess_stats": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
+    "tdgl_host_solve_gram": (C.c_int, [C.c_int32, c_f64p, c_f64p, c_f64p]),
     "tdgl_poisson_set_fused_level": (
         C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p]
     ),

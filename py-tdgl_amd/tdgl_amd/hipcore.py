@@ -116,7 +116,7 @@ class TDGLContext:
     # -- Poisson set-up -------------------------------------------------------------------
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
-                      cheb_lo=0.1, extrapolate=2, nu_fine=1) -> Hierarchy:
+                      cheb_lo=0.1, extrapolate=3, nu_fine=1) -> Hierarchy:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
         operators.py:305-308) + upload."""
         k = self._keep
@@ -341,17 +341,18 @@ class TDGLContext:
 
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
-                            extrapolate=2, nu_fine=1, fused_restriction=True, precond_fp32=True,
-                            collapse=True, tail_cycles=2):
+                            extrapolate=3, nu_fine=1, fused_restriction=True, precond_fp32=True,
+                            collapse=True, tail_cycles=2, guess_window=6):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
-                                int(extrapolate), int(nu_fine), int(bool(precond_fp32)))
+                                int(extrapolate), int(nu_fine), int(bool(precond_fp32)), int(guess_window))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
                                     fused_restriction=bool(fused_restriction), precond_fp32=bool(precond_fp32),
                                     edge_currents_every_step=bool(edge_currents_every_step),
-                                    collapse=bool(collapse), tail_cycles=int(tail_cycles))
+                                    collapse=bool(collapse), tail_cycles=int(tail_cycles),
+                                    guess_window=int(guess_window))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
         self._refresh_fused_restriction()
         self._refresh_collapsed()
@@ -583,6 +584,12 @@ class TDGLContext:
         out = (C.c_int64 * 3)()
         self._chk(self._lib.tdgl_get_poisson_stats(self._ctx, out))
         return dict(fp64_fallbacks=out[0], last_iterations=out[1], graph=bool(out[2]))
+
+    def guess_stats(self):
+        """``dict(vectors, initial_relres)`` of the last solve's initial guess."""
+        k, r = C.c_int32(0), C.c_double(0)
+        self._chk(self._lib.tdgl_get_guess_stats(self._ctx, C.byref(k), C.byref(r)))
+        return dict(vectors=k.value, initial_relres=r.value)
 
     def poisson_solve(self, rhs, mu0=None):
         rhs = f64(rhs)

@@ -431,3 +431,41 @@ def test_collapsed_coarse_operators_are_the_same_cycle():
 
     it1, it2 = iterations(collapsed_operators(h, tail_cycles=1)), iterations(collapsed_operators(h, tail_cycles=2))
     assert it2 <= it1
+
+
+def test_gram_solve_of_the_projection_guess():
+    """tdgl_host_solve_gram: c = pinv(G) rhs with directions below 1e-13 of the largest eigenvalue
+    (of the diagonally scaled matrix) dropped -- against numpy on nearly collinear bases like the
+    ones consecutive mu solutions form."""
+    import ctypes as C
+
+    from tdgl_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n = 400
+    t = np.linspace(0, 1, n)
+    for k in (1, 2, 4, 6, 8):
+        # smooth "trajectory": x_j = f(t_j), consecutive vectors differ by ~1e-2
+        X = np.column_stack([np.sin(3 * t + 0.01 * j) + 0.3 * np.cos(7 * t * (1 + 0.003 * j)) for j in range(k)])
+        A = np.diag(1.0 + rng.random(n))
+        G = X.T @ A @ X
+        b = A @ (np.sin(3 * t + 0.01 * k) + 0.3 * np.cos(7 * t * (1 + 0.003 * k)))
+        rhs = X.T @ b
+        c = np.zeros(k)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        Gc, rc = np.ascontiguousarray(G), np.ascontiguousarray(rhs)
+        assert lib.tdgl_host_solve_gram(k, f(Gc), f(rc), c.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        # reference: eigen-truncated solve of the scaled matrix
+        s = 1 / np.sqrt(np.diag(G))
+        w, V = np.linalg.eigh(G * s[:, None] * s[None, :])
+        keep = w > 1e-13 * w.max()
+        want = s * (V[:, keep] @ ((V[:, keep].T @ (s * rhs)) / w[keep]))
+        # compare through what matters: the A-norm error of the guess
+        err = lambda cc: np.sqrt((X @ cc - np.linalg.solve(A, b)) @ A @ (X @ cc - np.linalg.solve(A, b)))  # noqa: E731
+        assert err(c) <= 1.05 * err(want) + 1e-12, (k, err(c), err(want))
+        if k >= 4:
+            assert err(c) < 1e-3 * err(np.eye(k)[-1])  # far better than "previous solution"
+    bad = np.zeros((2, 2))
+    c = np.zeros(2)
+    assert lib.tdgl_host_solve_gram(2, f(bad), f(np.ones(2)), c.ctypes.data_as(C.POINTER(C.c_double))) != 0
