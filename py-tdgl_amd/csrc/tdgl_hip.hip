@@ -448,13 +448,17 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
     ctx->psi_status_pending = true;
 }
 
-// reduce the outcome of the last psi update into d_status (together with the PCG scalars)
-static void publish_status(tdgl_ctx *ctx) {
+// reduce the outcome of the last psi update into d_status (together with the PCG scalars);
+// guess_start: first synchronisation of a solve with the projection guess (sums its partial arrays,
+// sets S_BB / S_TOL2, resets the iteration counters); rr_part: residual partials to sum into S_RR
+static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double *rr_part = nullptr) {
     const bool psi = ctx->psi_status_pending;
     hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->d_status.p, ctx->scal.p,
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
-                       ctx->d_gdot.n ? ctx->d_gdot.p : (const double *)nullptr);
+                       ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
+                       guess_start ? ctx->part_gdot.p : (const double *)nullptr, (double)ctx->n_global,
+                       ctx->popt.rtol * ctx->popt.rtol, rr_part);
     ctx->psi_status_pending = false;
 }
 

@@ -121,6 +121,13 @@ struct AmgLevel {
 enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_CG_RZ0, S_CG_RZ1, S_CG_ALPHA0, S_CG_ALPHA1, S_RR0, S_COUNT = 12 };
 
 // what a step reports back to the host at its synchronisation point
+// arguments of the CG update x += alpha p, r -= alpha q (kernels.inc: xr_update_body)
+struct XrArgs {
+    const double *p, *q, *part_rz, *part_pq, *part_rr_in;
+    double *scal, *x, *r, *part_rr_out;
+    int64_t n;
+};
+
 constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels.inc: GK)
 
 struct StepStatus {
@@ -128,8 +135,8 @@ struct StepStatus {
     int32_t pad;
     unsigned long long dmax_bits[8];  // max | |psi'|^2 - |psi|^2 | as ordered uint64 bits, 8 slots
     double scal[S_COUNT];
-    // projection guess: x_j . b (j < GUESS_MAX), b . b, x_new . b_new of the previous solve
-    double gdot[GUESS_MAX + 2];
+    // projection guess: x_j . b (j < GUESS_MAX), b . b, x_new . b_new of the previous solve, sum b
+    double gdot[GUESS_MAX + 3];
 };
 
 }  // namespace tdgl
@@ -230,9 +237,11 @@ struct tdgl_ctx {
     int tail_level = -1;                  // -1: off
     int tail_mode = 0;                    // 0: e = B b (dense [n_t, n_t]);  1: y = G b, e = W b + V y
     int64_t tail_g_rows = 0;              // rows of G = columns of V
+    int64_t tail_ldg = 0, tail_ldv = 0;   // leading dimensions of G / V (padded to 4 entries)
     tdgl::DevBuf<double> tailG, tailV;    // dense row-major (mode 0: tailG holds B)
     tdgl::DevBuf<float> tailG32, tailV32;
     tdgl::Csr tailW;
+    tdgl::DevBuf<uint16_t> tailW_idx16;   // its column indices in 16 bits (the tail level has < 65536 rows)
     tdgl::DevBuf<double> tail_y;          // G b
     int tail_nu = 0, tail_smoother = 0;
     double tail_cheb_lo = 0.0;
@@ -243,6 +252,11 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
     tdgl::DevBuf<double> mu_prev, mu_prev2;  // mu^{n-1}, mu^{n-2} for the extrapolated initial guess
     double prev_dt = 0.0, prev_dt2 = 0.0;    // dt of the steps that produced mu / mu_prev (0: no history)
+    // lazy CG update (poisson.inc): the update of the previous iteration still to be applied while
+    // the current iteration's V-cycle is being queued; xr_carried = some launch of the coarse chain
+    // took it along
+    bool xr_active = false, xr_carried = false;
+    tdgl::XrArgs xr{};
     tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 1, 6};
     // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
     // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
@@ -253,7 +267,7 @@ struct tdgl_ctx {
     bool g_diag_pending = false;
     double g_G[tdgl::GUESS_MAX][tdgl::GUESS_MAX] = {{0}};
     double g_rhs[tdgl::GUESS_MAX] = {0};
-    tdgl::DevBuf<double> part_gdot;       // (GUESS_MAX + 2) x NB partials: [x_j . b | b . b | x_new . b_new]
+    tdgl::DevBuf<double> part_gdot;       // (GUESS_MAX + 3) x NB partials: [x_j . b | b . b | x_new . b_new | sum b]
     tdgl::DevBuf<double> d_gdot;          // their sums
     int32_t last_guess_vectors = 0;       // basis size the last guess was formed from
     double last_guess_relres = 0.0;

@@ -5,7 +5,10 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 : > $OUT/AB_${TAG}.jsonl
 for V in "$@"; do
-  timeout 900 python bench.py --no-cpu-baseline $V > $OUT/ab_tmp.json 2> $OUT/ab_${TAG}_last.err || { echo "FAILED: $V"; tail -5 $OUT/ab_${TAG}_last.err; }
+  # "ENV=1 OTHER=2 @ --args": environment assignments before the @
+  E=""; A="$V"
+  case "$V" in *@*) E="${V%%@*}"; A="${V#*@}";; esac
+  timeout 900 env $E python bench.py --no-cpu-baseline $A > $OUT/ab_tmp.json 2> $OUT/ab_${TAG}_last.err || { echo "FAILED: $V"; tail -5 $OUT/ab_${TAG}_last.err; }
   python - "$V" <<'PY' >> $OUT/AB_${TAG}.jsonl
 import json,sys
 try:
