@@ -265,6 +265,21 @@ int tdgl_get_link_scale(tdgl_ctx *ctx, double *scale);
 int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon);
 /* self.mu_boundary (solver.py:289, 325-345): indexed by position in boundary_edge_indices. */
 int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary);
+/* Time-dependent terminal currents and disorder without a host round trip per step: piecewise-linear
+ * tables (constant outside the node range) that tdgl_run evaluates at the time of every step, the way
+ * tdgl_set_link_ramp does for A(t).
+ *   tdgl_set_mu_boundary_table: update_mu_boundary (solver.py:325-345) for tabulated currents.  Group g
+ *     (one per terminal) covers the boundary-edge POSITIONS group_pos[group_ptr[g] .. group_ptr[g+1])
+ *     and carries the current density density[g * n_nodes + k] at times[k] (already
+ *     -(1/length_g) * sum of the other terminals' currents); mu_boundary is refreshed only in steps
+ *     where a density changed, like the reference.  Densities and mu_boundary start at 0.
+ *   tdgl_set_epsilon_table: epsilon(r, t) = factor(t) * epsilon0(r) (update_epsilon, solver.py:364-381,
+ *     for a separable disorder parameter).
+ * n_nodes = 0 switches a table off. */
+int tdgl_set_mu_boundary_table(tdgl_ctx *ctx, int32_t n_nodes, const double *times, int32_t n_groups,
+                               const int32_t *group_ptr, const int32_t *group_pos, const double *density);
+int tdgl_set_epsilon_table(tdgl_ctx *ctx, const double *epsilon0, int32_t n_nodes, const double *times,
+                           const double *factor);
 /* Initial / seed values of psi [n] complex and mu [n] (solver.py:284-288, 732-752). */
 int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu);
 /* SolverOptions fields + resets the controller state (tentative_dt = dt_init,

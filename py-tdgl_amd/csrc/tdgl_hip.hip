@@ -488,6 +488,7 @@ static void refresh_ceff(tdgl_ctx *ctx) {
 }
 
 static int update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev);  // below
+static int apply_time_tables(tdgl_ctx *ctx);                                 // below
 
 #include "comm.inc"
 #include "poisson.inc"
@@ -629,9 +630,8 @@ extern "C" int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon) {
     return TDGL_OK;
 }
 
-extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
-    CTX_GUARD(ctx);
-    if (ctx->nb > 0 && !mu_boundary) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_mu_boundary: null array");
+// mu_boundary -> boundary term of the Poisson right-hand side (everything queued on the stream)
+static int apply_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->cvec.p, 0, ctx->n_pad * sizeof(double), ctx->stream));
     if (ctx->nb > 0) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->b_mu.p, mu_boundary, ctx->nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -640,7 +640,100 @@ extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
     }
     refresh_ceff(ctx);
     HIP_TRY(ctx, hipGetLastError());
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
+    CTX_GUARD(ctx);
+    if (ctx->nb > 0 && !mu_boundary) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_mu_boundary: null array");
+    TDGL_TRY(apply_mu_boundary(ctx, mu_boundary));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->tab_mu_host.empty() && ctx->nb > 0) ctx->tab_mu_host.assign(mu_boundary, mu_boundary + ctx->nb);
+    return TDGL_OK;
+}
+
+// ---- piecewise-linear time tables, evaluated inside tdgl_run ------------------------------------
+// value at time t of the table (t_k, v_k): linear between nodes, constant outside
+static double table_value(const std::vector<double> &t, const double *v, double time) {
+    const size_t n = t.size();
+    if (n == 0) return 0.0;
+    if (time <= t[0]) return v[0];
+    if (time >= t[n - 1]) return v[n - 1];
+    const size_t k = std::upper_bound(t.begin(), t.end(), time) - t.begin();  // t[k-1] <= time < t[k]
+    const double t0 = t[k - 1], t1 = t[k];
+    return v[k - 1] + (v[k] - v[k - 1]) * ((time - t0) / (t1 - t0));
+}
+
+static bool table_times_ok(const double *times, int32_t n) {
+    for (int32_t k = 0; k < n; ++k)
+        if (!std::isfinite(times[k]) || (k > 0 && !(times[k] > times[k - 1]))) return false;
+    return true;
+}
+
+extern "C" int tdgl_set_mu_boundary_table(tdgl_ctx *ctx, int32_t n_nodes, const double *times, int32_t n_groups,
+                                          const int32_t *group_ptr, const int32_t *group_pos, const double *density) {
+    CTX_GUARD(ctx);
+    ctx->tab_mu_t.clear();
+    ctx->tab_mu_host.clear();
+    if (n_nodes == 0) return TDGL_OK;  // off
+    if (n_nodes < 1 || n_groups < 1 || !times || !group_ptr || !group_pos || !density || !table_times_ok(times, n_nodes))
+        TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_mu_boundary_table: bad table (times must increase strictly)");
+    for (int32_t k = 0; k < group_ptr[n_groups]; ++k)
+        if (group_pos[k] < 0 || group_pos[k] >= ctx->nb)
+            TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_mu_boundary_table: boundary position %d out of range", group_pos[k]);
+    ctx->tab_mu_t.assign(times, times + n_nodes);
+    ctx->tab_mu_dens.assign(density, density + (size_t)n_groups * n_nodes);
+    ctx->tab_mu_ptr.assign(group_ptr, group_ptr + n_groups + 1);
+    ctx->tab_mu_pos.assign(group_pos, group_pos + group_ptr[n_groups]);
+    ctx->tab_mu_last.assign(n_groups, 0.0);                        // solver.py:323: densities start at 0
+    ctx->tab_mu_host.assign(std::max<int64_t>(ctx->nb, 1), 0.0);  // ... and mu_boundary at 0 (solver.py:289)
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_set_epsilon_table(tdgl_ctx *ctx, const double *epsilon0, int32_t n_nodes, const double *times,
+                                      const double *factor) {
+    CTX_GUARD(ctx);
+    ctx->tab_eps_t.clear();
+    if (n_nodes == 0) return TDGL_OK;  // off
+    if (n_nodes < 1 || !epsilon0 || !times || !factor || !table_times_ok(times, n_nodes))
+        TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_epsilon_table: bad table (times must increase strictly)");
+    if (ctx->tab_eps0.n == 0) HIP_TRY(ctx, ctx->tab_eps0.alloc(ctx->n_pad));
+    TDGL_TRY(upload_sites(ctx, epsilon0, ctx->tab_eps0));
+    ctx->tab_eps_t.assign(times, times + n_nodes);
+    ctx->tab_eps_f.assign(factor, factor + n_nodes);
+    ctx->tab_eps_last = NAN;
+    return TDGL_OK;
+}
+
+// update_mu_boundary (solver.py:325-345) and update_epsilon (solver.py:364-381) for tabulated inputs,
+// at the time of the step about to be taken
+static int apply_time_tables(tdgl_ctx *ctx) {
+    if (!ctx->tab_mu_t.empty()) {
+        const size_t nn = ctx->tab_mu_t.size(), ng = ctx->tab_mu_last.size();
+        bool changed = false;
+        for (size_t g = 0; g < ng; ++g) {
+            const double d = table_value(ctx->tab_mu_t, ctx->tab_mu_dens.data() + g * nn, ctx->time);
+            if (d != ctx->tab_mu_last[g]) {  // solver.py:341: only when the density changed
+                ctx->tab_mu_last[g] = d;
+                for (int32_t k = ctx->tab_mu_ptr[g]; k < ctx->tab_mu_ptr[g + 1]; ++k) ctx->tab_mu_host[ctx->tab_mu_pos[k]] = d;
+                changed = true;
+            }
+        }
+        if (changed) {
+            // (the copy of tab_mu_host is asynchronous: wait before the host array can change again)
+            TDGL_TRY(apply_mu_boundary(ctx, ctx->tab_mu_host.data()));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    if (!ctx->tab_eps_t.empty()) {
+        const double f = table_value(ctx->tab_eps_t, ctx->tab_eps_f.data(), ctx->time);
+        if (!(f == ctx->tab_eps_last)) {
+            hipLaunchKernelGGL(k_scale_links, dim3(grid_for(ctx->n_pad)), dim3(BLOCK), 0, ctx->stream, ctx->n_pad, f,
+                               (const double *)ctx->tab_eps0.p, ctx->eps.p);
+            ctx->tab_eps_last = f;
+            ctx->have_eps = true;
+        }
+    }
     return TDGL_OK;
 }
 

@@ -200,6 +200,15 @@ struct tdgl_ctx {
     bool ramp_on = false;
     double ramp_tmin = 0.0, ramp_tmax = 1.0, ramp_initial = 0.0, ramp_final = 1.0;
     double link_scale = 1.0, link_scale_prev = 1.0;  // scale of the current / previous A
+    // Piecewise-linear time tables evaluated by tdgl_run itself before every step (no Python round
+    // trip per step): terminal current densities -> mu_boundary (tdgl_set_mu_boundary_table) and a
+    // time-dependent factor of epsilon (tdgl_set_epsilon_table)
+    std::vector<double> tab_mu_t, tab_mu_dens;       // nodes; densities [n_groups x n_nodes]
+    std::vector<int32_t> tab_mu_ptr, tab_mu_pos;     // groups of boundary-edge positions (CSR-like)
+    std::vector<double> tab_mu_last, tab_mu_host;    // last densities applied; host copy of mu_boundary
+    std::vector<double> tab_eps_t, tab_eps_f;
+    tdgl::DevBuf<double> tab_eps0;                   // static part of epsilon, internal site order
+    double tab_eps_last = NAN;
     // boundary term: c = mu_boundary_laplacian @ mu_boundary
     tdgl::DevBuf<int32_t> b_s0, b_s1;
     tdgl::DevBuf<double> b_c0, b_c1, b_mu;

@@ -9,7 +9,9 @@ from . import geometry  # noqa: F401
 from .device import Device, Layer, Polygon, TerminalInfo  # noqa: F401
 from .finite_volume import EdgeMesh, Mesh  # noqa: F401
 from .operators import MeshOperators  # noqa: F401
-from .parameter import ConstantField, LinearRamp, Parameter  # noqa: F401
+from .parameter import (  # noqa: F401
+    ConstantField, LinearRamp, Parameter, PiecewiseLinear, SeparableEpsilon, TabulatedCurrents,
+)
 from .options import SolverOptions, SolverOptionsError, SparseSolver  # noqa: F401
 from .solution import Solution  # noqa: F401
 from .solver import SolverResult, TDGLSolver, solve  # noqa: F401

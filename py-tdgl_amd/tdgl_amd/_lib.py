@@ -172,6 +172,8 @@ SIGNATURES = {
     "tdgl_update_link_exponents": (C.c_int, [_CTX, c_f64p, C.c_double]),
     "tdgl_set_epsilon": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_mu_boundary": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_set_mu_boundary_table": (C.c_int, [_CTX, C.c_int32, c_f64p, C.c_int32, c_i32p, c_i32p, c_f64p]),
+    "tdgl_set_epsilon_table": (C.c_int, [_CTX, c_f64p, C.c_int32, c_f64p, c_f64p]),
     "tdgl_set_state": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_set_controller": (C.c_int, [_CTX, C.POINTER(Controller)]),
     "tdgl_set_probes": (C.c_int, [_CTX, c_i32p, C.c_int32]),

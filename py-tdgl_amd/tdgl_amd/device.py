@@ -81,6 +81,13 @@ class Layer:
             z0=self.z0,
         )
 
+    def to_hdf5(self, h5_group) -> None:
+        """`tdgl/device/layer.py:59-72`."""
+        for k in ("london_lambda", "coherence_length", "thickness", "u", "gamma", "z0"):
+            h5_group.attrs[k] = getattr(self, k)
+        if self.conductivity is not None:
+            h5_group.attrs["conductivity"] = self.conductivity
+
     def __repr__(self):
         return (
             f"Layer(london_lambda={self.london_lambda}, coherence_length={self.coherence_length},"
@@ -135,6 +142,13 @@ class Polygon:
         if area2 < 0:
             pts = pts[::-1]
         self._points = pts
+
+    def to_hdf5(self, h5_group) -> None:
+        """`tdgl/device/polygon.py:581-586`."""
+        if self.name is not None:
+            h5_group.attrs["name"] = self.name
+        h5_group.attrs["mesh"] = self.mesh
+        h5_group["points"] = self.points
 
     @property
     def area(self) -> float:
@@ -234,6 +248,27 @@ class Device:
         _unit(LENGTH_UNITS, length_units, "length")
         self._length_units = length_units
         self.mesh: Optional[Mesh] = None
+
+    def to_hdf5(self, h5_group, save_mesh: bool = True) -> None:
+        """Serialise into an open HDF5 group in the reference's layout (`tdgl/device/device.py:772-809`)."""
+        from .io import write_mesh
+
+        h5_group.attrs["name"] = self.name
+        h5_group.attrs["length_units"] = self.length_units
+        self.layer.to_hdf5(h5_group.create_group("layer"))
+        self.film.to_hdf5(h5_group.create_group("film"))
+        if self.terminals:
+            grp = h5_group.create_group("terminals")
+            for terminal in self.terminals:
+                terminal.to_hdf5(grp.create_group(terminal.name))
+        if self.probe_points is not None:
+            h5_group["probe_points"] = self.probe_points
+        if self.holes:
+            grp = h5_group.create_group("holes")
+            for hole in sorted(self.holes, key=lambda h: h.name):
+                hole.to_hdf5(grp.create_group(hole.name))
+        if save_mesh and self.mesh is not None:
+            write_mesh(h5_group.create_group("mesh"), self.mesh)
 
     # -- units and scales -----------------------------------------------------------------
     @property

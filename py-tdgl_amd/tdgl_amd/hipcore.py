@@ -401,6 +401,30 @@ class TDGLContext:
         assert mu_b.shape == (self.n_boundary,)
         self._chk(self._lib.tdgl_set_mu_boundary(self._ctx, p_f64(mu_b)))
 
+    def set_mu_boundary_table(self, times, groups, densities):
+        """Tabulated terminal current densities evaluated inside `run` (``groups[g]`` = boundary-edge
+        positions of terminal g, ``densities[g, k]`` at ``times[k]``); ``times=None`` switches it off."""
+        if times is None:
+            self._chk(self._lib.tdgl_set_mu_boundary_table(self._ctx, 0, None, 0, None, None, None))
+            return
+        t, d = f64(times), f64(densities)
+        ptr = i32(np.concatenate([[0], np.cumsum([len(g) for g in groups])]))
+        pos = i32(np.concatenate([np.asarray(g, dtype=np.int64) for g in groups]) if len(groups) else [])
+        if d.shape != (len(groups), len(t)):
+            raise ValueError(f"densities must have shape ({len(groups)}, {len(t)}), got {d.shape}")
+        self._chk(self._lib.tdgl_set_mu_boundary_table(self._ctx, len(t), p_f64(t), len(groups), p_i32(ptr),
+                                                       p_i32(pos) if len(pos) else p_i32(i32([0])), p_f64(d)))
+
+    def set_epsilon_table(self, epsilon0, times, factors):
+        """epsilon(r, t) = factor(t) * epsilon0(r) evaluated inside `run`; ``times=None``: off."""
+        if times is None:
+            self._chk(self._lib.tdgl_set_epsilon_table(self._ctx, None, 0, None, None))
+            return
+        e0, t, fac = f64(np.broadcast_to(epsilon0, (self.n,))), f64(times), f64(factors)
+        if t.shape != fac.shape:
+            raise ValueError("times and factors must have the same length")
+        self._chk(self._lib.tdgl_set_epsilon_table(self._ctx, p_f64(e0), len(t), p_f64(t), p_f64(fac)))
+
     def set_state(self, psi, mu):
         psi, mu = c128(psi), f64(mu)
         assert psi.shape == (self.n,) and mu.shape == (self.n,)

@@ -146,3 +146,54 @@ def LinearRamp(tmin: float = 0, tmax: float = 10, initial: float = 0, final: flo
     p.uniform_in_space = True
     p.ramp = dict(tmin=float(tmin), tmax=float(tmax), initial=float(initial), final=float(final))
     return p
+
+
+# ---- tabulated time dependence, evaluated on the device ------------------------------------------
+class PiecewiseLinear:
+    """``f(t)``: linear between the nodes ``(times[k], values[k])``, constant outside.  Time-dependent
+    inputs given in this form are uploaded once and evaluated by the time loop itself
+    (`tdgl_set_mu_boundary_table` / `tdgl_set_epsilon_table`): no Python call, no upload per step."""
+
+    def __init__(self, times, values):
+        self.times = np.asarray(times, dtype=float)
+        self.values = np.asarray(values, dtype=float)
+        if self.times.ndim != 1 or self.times.shape != self.values.shape or len(self.times) < 1:
+            raise ValueError("times and values must be one-dimensional and of equal length")
+        if np.any(np.diff(self.times) <= 0):
+            raise ValueError("times must increase strictly")
+
+    def __call__(self, t) -> float:
+        return float(np.interp(t, self.times, self.values))
+
+
+class TabulatedCurrents:
+    """``terminal_currents`` as tables: ``TabulatedCurrents(times, dict(source=[...], drain=[...]))``.
+    Callable like any ``t -> {name: current}`` function (so it works wherever the reference's
+    callable does); the solver uploads the tables and the device evaluates them per step."""
+
+    def __init__(self, times, currents):
+        self.times = np.asarray(times, dtype=float)
+        self.tables = {name: PiecewiseLinear(self.times, v) for name, v in currents.items()}
+
+    def __call__(self, t):
+        return {name: f(t) for name, f in self.tables.items()}
+
+    def scaled(self, factor: float) -> "TabulatedCurrents":
+        return TabulatedCurrents(self.times, {name: factor * f.values for name, f in self.tables.items()})
+
+
+class SeparableEpsilon:
+    """``disorder_epsilon(r, t) = factor(t) * static(r)``: ``static`` an array over the sites or a
+    callable ``static(r[n, 2]) -> [n]``, ``factor`` a `PiecewiseLinear`.  Has the reference's calling
+    convention (``epsilon(r, *, t, vectorized=True)``, `tdgl/solver/solver.py:191-216`); the solver
+    keeps ``static`` on the device and evaluates ``factor`` inside the time loop."""
+
+    def __init__(self, static, factor: PiecewiseLinear):
+        self.static, self.factor = static, factor
+
+    def static_values(self, sites) -> np.ndarray:
+        s = self.static(np.asarray(sites)) if callable(self.static) else self.static
+        return np.asarray(s, dtype=float) * np.ones(len(sites))
+
+    def __call__(self, r, *, t=0.0, vectorized=True):
+        return self.factor(t) * self.static_values(np.atleast_2d(r))

@@ -1,9 +1,11 @@
-"""In-memory result of a simulation.
+"""Result of a simulation.
 
 The reference's ``Solution`` (`tdgl/solution/solution.py:59-1090`) wraps an HDF5 file and
-offers post-processing/plotting; that layer is out of scope here (h5py is not on the target
-image).  This class carries what the solver produced: the fields at every saved step, the
-per-step scalars (``dt``, probe ``mu``/``theta``) and the configuration.
+offers post-processing/plotting; that layer is out of scope here.  This class carries what the
+solver produced: the fields at every saved step (without ``SolverOptions.output_file``) or at the
+last saved step (with it: the others were streamed to ``path`` in the reference's layout,
+`tdgl_amd.io.DataHandler`), the per-step scalars (``dt``, probe ``mu``/``theta``) and the
+configuration.
 """
 
 from dataclasses import dataclass, field
@@ -61,6 +63,8 @@ class Solution:
     solve_step: int = -1
     dynamic_vector_potential: bool = False
     dynamic_epsilon: bool = False
+    path: Optional[str] = None                 # the streamed HDF5 file (SolverOptions.output_file)
+    saved_step_index: Optional[list] = None    # streaming: (step, time) of every group data/<k> on disk
 
     def to_hdf5(self, file) -> None:
         """Write the saved steps in the reference's DataHandler layout (`tdgl_amd.io`); ``file``

@@ -144,6 +144,12 @@ class TDGLSolver:
         # ---- disorder parameter epsilon on the sites (solver.py:191-216) ----------------
         self.epsilon_func = None
         self.dynamic_epsilon = False
+        self._eps_table = None
+        from .parameter import SeparableEpsilon, TabulatedCurrents
+
+        if isinstance(disorder_epsilon, SeparableEpsilon):  # factor(t) * static(r): evaluated on the device
+            eps0 = disorder_epsilon.static_values(self.sites)
+            self._eps_table = (eps0, disorder_epsilon.factor.times, disorder_epsilon.factor.values)
         if callable(disorder_epsilon):
             spec = inspect.getfullargspec(disorder_epsilon)
             self.dynamic_epsilon = "t" in spec.kwonlyargs
@@ -192,6 +198,7 @@ class TDGLSolver:
                 return const
 
         J_scale = device.current_scale(options.current_units)
+        self._current_table = terminal_currents.scaled(J_scale) if isinstance(terminal_currents, TabulatedCurrents) else None
         self.current_func = lambda t: {k: J_scale * v for k, v in raw_func(t).items()}
         validate_terminal_currents(self.current_func, self.terminal_info, options)
         # ---- screening (solver.py:305-309) ------------------------------------------------------
@@ -258,6 +265,10 @@ class TDGLSolver:
             for t in terminal_info]
         self.terminal_info = tuple(sorted(info, key=lambda t: t.length))
         self.terminal_names = [t.name for t in self.terminal_info]
+        from .parameter import TabulatedCurrents
+
+        self._current_table = current_func if isinstance(current_func, TabulatedCurrents) else None
+        self._eps_table = None
         self.dynamic_currents = callable(current_func)
         if not self.dynamic_currents:  # None or a constant {name: current} dict
             const = {name: 0 for name in self.terminal_names}
@@ -324,11 +335,31 @@ class TDGLSolver:
                 max_iterations=options.max_iterations_per_step, tolerance=options.screening_tolerance,
                 step_size=options.screening_step_size, step_drag=options.screening_step_drag,
             )
+        # tabulated time dependence: uploaded once, evaluated by tdgl_run at every step's time
+        self._currents_on_device = self._epsilon_on_device = False
+        if self._current_table is not None and self.terminal_info:
+            tab = self._current_table
+            names = self.terminal_names
+            dens = np.array([
+                (-1.0 / term.length) * sum(tab.tables[nm].values for nm in names if nm != term.name and nm in tab.tables)
+                * np.ones(len(tab.times))
+                for term in self.terminal_info
+            ])
+            self.ctx.set_mu_boundary_table(tab.times, [np.asarray(t.boundary_edge_indices) for t in self.terminal_info], dens)
+            self._currents_on_device = True
+        if self._eps_table is not None:
+            eps0, times, values = self._eps_table
+            if max(float(np.max(f * eps0)) for f in values) > 1:
+                raise ValueError("The disorder parameter epsilon must be <= 1")
+            self.ctx.set_epsilon_table(eps0, times, values)
+            self._epsilon_on_device = True
         self._device_holds = None  # (psi, mu) arrays known to equal the device state
 
     # -- boundary conditions --------------------------------------------------------------------
     def update_mu_boundary(self, time: float) -> bool:
         """solver.py:325-345.  Returns True if mu_boundary changed (and was re-uploaded)."""
+        if self._currents_on_device:
+            return False  # tdgl_run evaluates the tables itself (tdgl_set_mu_boundary_table)
         currents = self.current_func(time)
         changed = False
         for term in self.terminal_info:
@@ -353,7 +384,9 @@ class TDGLSolver:
         elif self.dynamic_vector_potential:
             self.current_A_applied = np.asarray(self.vector_potential_func(time), dtype=float)
             self.ctx.update_link_exponents(self.current_A_applied, dt_prev)
-        if self.dynamic_epsilon:
+        if self.dynamic_epsilon and self._epsilon_on_device:
+            self.epsilon = np.asarray(self.epsilon_func(time), dtype=float)  # host copy for the saved steps
+        elif self.dynamic_epsilon:
             self.epsilon = np.asarray(self.epsilon_func(time), dtype=float)
             if np.any(self.epsilon > 1):
                 raise ValueError("The disorder parameter epsilon must be <= 1")
@@ -432,9 +465,34 @@ class TDGLSolver:
         saved = []
         dyn = dict(dt=[], time=[], mu=[], theta=[], iters=[], scr=[])
         n_steps = {"Thermalizing": 0, "Simulating": 0}
+        # Streaming output (runner.py:104-183): with SolverOptions.output_file every saved step is
+        # written when it is taken, and only the latest one is kept in memory.
+        handler = None
+        sizes = {"dt": 1}
+        if self.probe_points is not None:
+            sizes["mu"] = sizes["theta"] = len(self.probe_points)
+        if self.screening is not None:
+            sizes["screening_iterations"] = 1
+        from .io import DataHandler, RunningState, write_solution_group
 
-        def save_step():
+        running = RunningState(sizes, opts.save_every)
+        if opts.output_file is not None:
+            handler = DataHandler(opts.output_file, file_factory=getattr(self, "_h5_file_factory", None)).__enter__()
+            handler.save_mesh(self.device.mesh)
+            fixed = {}
+            if not self.dynamic_vector_potential:
+                fixed["applied_vector_potential"] = self.current_A_applied
+            if not self.dynamic_epsilon:
+                fixed["epsilon"] = self.epsilon
+            handler.save_fixed_values(fixed)
+
+        def save_step(final=False):
             ls = ctx.loop_state()
+            if self.dynamic_epsilon and self._epsilon_on_device:
+                # the reference saves the epsilon its last update() evaluated (solver.py:645-648): at the
+                # time of the last step taken
+                t_last = ls["time"] if (final or ls["step"] == 0) else ls["time"] - ls["dt"]
+                self.epsilon = np.asarray(self.epsilon_func(max(t_last, 0.0)), dtype=float)
             if ls["step"] == 0 and not saved and self.seed_solution is None:
                 js = jn = np.zeros(self.num_edges)  # reference initial values (solver.py:736-737)
                 st = ctx.get_state(supercurrent=False, normal_current=False)
@@ -444,17 +502,35 @@ class TDGLSolver:
             a_ind = ctx.induced_vector_potential() if self.screening is not None else None
             if self._A_base is not None:
                 self.current_A_applied = ctx.link_scale() * self._A_base
-            saved.append(TDGLData(ls["step"], ls["time"], ls["dt"], st["psi"], st["mu"], js, jn,
-                                  applied_vector_potential=self.current_A_applied, epsilon=self.epsilon,
-                                  induced_vector_potential=a_ind))
+            data = TDGLData(ls["step"], ls["time"], ls["dt"], st["psi"], st["mu"], js, jn,
+                            applied_vector_potential=self.current_A_applied, epsilon=self.epsilon,
+                            induced_vector_potential=a_ind)
+            if handler is None:
+                saved.append(data)
+                return
+            fields = dict(psi=data.psi, mu=data.mu, supercurrent=js, normal_current=jn,
+                          induced_vector_potential=np.zeros((self.num_edges, 2)) if a_ind is None else a_ind)
+            if self.dynamic_vector_potential:
+                fields["applied_vector_potential"] = self.current_A_applied
+            if self.dynamic_epsilon:
+                fields["epsilon"] = self.epsilon
+            state = dict(step=int(ls["step"]), time=float(ls["time"]), dt=float(ls["dt"]))
+            handler.save_time_step(state, fields, None if ls["step"] == 0 else running.export())
+            saved[:] = [data]
+            saved_meta.append((data.step, data.time))
+
+        saved_meta = []
 
         def run_stage(name, end_time, save):
             ctx.begin_stage()
             i = 0
             while True:
-                if save and i % opts.save_every == 0:
-                    save_step()
-                per_step = (self.dynamic_currents or self.dynamic_epsilon
+                if i % opts.save_every == 0:  # runner.py:398-401
+                    if save:
+                        save_step()
+                    running.clear()
+                per_step = ((self.dynamic_currents and not self._currents_on_device)
+                            or (self.dynamic_epsilon and not self._epsilon_on_device)
                             or (self.dynamic_vector_potential and self._A_ramp is None))
                 chunk = 1 if per_step else opts.save_every - (i % opts.save_every)
                 ls = ctx.loop_state()
@@ -464,6 +540,16 @@ class TDGLSolver:
                 res = ctx.run(chunk, end_time)
                 k = len(res["dt"])
                 n_steps[name] += k
+                cols = {"dt": res["dt"]}
+                if res["mu"] is not None:
+                    cols["mu"], cols["theta"] = res["mu"], res["theta"]
+                if self.screening is not None:
+                    cols["screening_iterations"] = res["screening_iterations"]
+                # (the step that ends the loop is written into the buffer but not counted, runner.py:429-432)
+                running.extend({name_: v[:k - 1] if res["reached_end"] else v for name_, v in cols.items()})
+                if res["reached_end"]:
+                    for name_, v in cols.items():
+                        running.append(name_, np.asarray(v[k - 1]).reshape(-1))
                 if save:
                     dyn["dt"].append(res["dt"])
                     times = t_before + np.concatenate([[0.0], np.cumsum(res["dt"][:-1])])
@@ -478,12 +564,17 @@ class TDGLSolver:
                     break
                 i += k
             if save and (i % opts.save_every):
-                save_step()
+                save_step(final=True)
 
-        if opts.skip_time:
-            run_stage("Thermalizing", opts.skip_time, False)
-        run_stage("Simulating", opts.solve_time, True)
-        ctx.synchronize()
+        try:
+            if opts.skip_time:
+                run_stage("Thermalizing", opts.skip_time, False)
+            run_stage("Simulating", opts.solve_time, True)
+            ctx.synchronize()
+        except BaseException:
+            if handler is not None:  # what has been saved stays on disk
+                handler.close()
+            raise
         total = _time.perf_counter() - t_start
         cat = lambda xs: np.concatenate(xs) if xs else np.array([])  # noqa: E731
         dynamics = DynamicsData(
@@ -511,8 +602,11 @@ class TDGLSolver:
                 mean_pcg_iterations=float(dynamics.pcg_iterations.mean()) if len(dynamics.pcg_iterations) else 0.0,
             ),
         )
-        if opts.output_file is not None:  # the reference streams into this file; here: at the end
-            solution.to_hdf5(opts.output_file)
+        if handler is not None:
+            solution.path = handler.output_path
+            solution.saved_step_index = saved_meta  # (step, time) of every group data/<k> on disk
+            write_solution_group(handler.output_file, solution)  # solver.py:815-826 -> Solution.to_hdf5()
+            handler.close()
         return solution
 
 

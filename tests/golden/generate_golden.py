@@ -299,9 +299,56 @@ def gen_dynamic_lag(small):
          **{"ramp_" + k: v for k, v in ramp.items()}, **options_arrays(o), **out)
 
 
+def gen_device_meshes():
+    """Trajectories on real device meshes, run by the reference on meshes
+    already committed as fixtures (so the meshes are not regenerated):
+
+    * traj_transport_polygon: the reference's own test device shape (tdgl/test/conftest.py:7-49:
+      10x10 box united with a 30x4 strip, two round holes, current terminals on the strip ends, probe
+      points on the strip, weak field) on `mesh_polygon` (constrained Delaunay mesh of the polygon);
+    * traj_irregular_smoothed: a Laplacian-smoothed, non-Delaunay mesh whose boundary cells take the
+      reference's convex-hull area branch (tdgl/finite_volume/util.py:169-255), uniform field."""
+    def load(name):
+        with np.load(os.path.join(HERE, name + ".npz")) as f:
+            return {k: f[k] for k in f.files}
+
+    gp = load("mesh_polygon")
+    poly = RefMesh.from_triangulation(gp["mesh_sites"], gp["mesh_elements"])
+    assert np.array_equal(poly.edge_mesh.edges, gp["mesh_edges"]) and np.allclose(poly.areas, gp["mesh_areas"], rtol=0, atol=0)
+    terms = [edge_terminal(poly, "source", -15.0), edge_terminal(poly, "drain", 15.0)]
+    probes = [poly.closest_site((-10, 0)), poly.closest_site((10, 0))]
+    o = SolverOptions(solve_time=12.0, skip_time=2.0, dt_init=1e-4, save_every=100)
+    cur = {"source": 1.0, "drain": -1.0}
+    s, psi0, fx = make_ref_solver(poly, uniform_field_A(poly, 0.15), o, terminals=terms, currents=cur,
+                                  probe_points=probes)
+    out = run_reference(s, psi0, o, snapshot_steps=(10, 150))
+    print("transport_polygon calls:", len(out["call_dt"]), "V", out["call_mu_probe"][-1],
+          "min|psi|^2", (np.abs(out["final_psi"]) ** 2).min())
+    term_arrays = {}
+    for t in terms:
+        term_arrays[f"term_{t.name}_sites"] = t.site_indices
+        term_arrays[f"term_{t.name}_edges"] = t.edge_indices
+        term_arrays[f"term_{t.name}_boundary_pos"] = t.boundary_edge_indices
+        term_arrays[f"term_{t.name}_length"] = t.length
+    save("traj_transport_polygon", b=0.15, current=1.0, probe_points=np.array(probes), fixed_sites=fx,
+         mu_boundary=s.mu_boundary, **term_arrays, **options_arrays(o), **out)
+
+    gs = load("mesh_irregular_smoothed")
+    sm = RefMesh.from_triangulation(gs["mesh_sites"], gs["mesh_elements"])
+    assert np.allclose(sm.areas, gs["mesh_areas"], rtol=0, atol=0)
+    o = SolverOptions(solve_time=6.0, dt_init=1e-4, save_every=100)
+    s, psi0, _ = make_ref_solver(sm, uniform_field_A(sm, 0.9), o)
+    out = run_reference(s, psi0, o, snapshot_steps=(5, 120))
+    print("irregular_smoothed calls:", len(out["call_dt"]), "min|psi|^2", (np.abs(out["final_psi"]) ** 2).min())
+    save("traj_irregular_smoothed", b=0.9, **options_arrays(o), **out)
+
+
 def main():
     if "--dynamic-lag-only" in sys.argv:
         gen_dynamic_lag(make_ref_mesh(20, 20))
+        return
+    if "--device-meshes-only" in sys.argv:
+        gen_device_meshes()
         return
     # ---- (1) meshes ---------------------------------------------------------------
     small = make_ref_mesh(20, 20)  # 516 sites
@@ -491,6 +538,7 @@ def main():
          **options_arrays(o), **out)
 
     gen_dynamic_lag(small)
+    gen_device_meshes()
 
     # (4h) screening (solver.py:522-578, 654-688; tdgl/solver/screening.py:12-42): the induced
     # vector potential is iterated to self-consistency inside every step.  Tiny mesh: without

@@ -146,3 +146,73 @@ def test_device_with_holes_and_terminals_runs_and_conserves_current():
     # a cut through the box passes the holes: the current through the film is still I
     assert np.isclose(solution.current_through_cut(0.013 / xi) / j_scale * xi, 10.0, rtol=1e-6)
     assert np.abs(solution.tdgl_data.psi).max() < 1.2  # transient overshoot near phase slips is physical
+
+
+def test_output_file_is_streamed_in_the_reference_layout(tmp_path, monkeypatch):
+    """SolverOptions.output_file: every saved step is written when it is taken
+    (DataHandler.save_time_step, tdgl/solver/runner.py:155-183), the latest step also into the
+    `.tmp` file of the reference's monitor; only the last step stays in memory.  h5py is not on the
+    image, so every h5py call lands in an in-memory recorder (tests/h5_recorder.py).  Compared with
+    the same run held in memory; a run that dies keeps what it had saved."""
+    import sys
+
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).parent))
+    import h5_recorder as rec
+    import tdgl_amd as tdgl
+    from tdgl_amd import io as tio
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(tio, "_h5py_factory", rec.RecorderFile)
+    rec.OPENED.clear()
+    device = _transport_device()
+    cur = dict(source=5.0, drain=-5.0)
+    kw = dict(solve_time=3, skip_time=0.5, dt_init=1e-3, field_units="uT", current_units="uA", save_every=40)
+    mem = tdgl.solve(device, tdgl.SolverOptions(**kw), applied_vector_potential=1.0, terminal_currents=cur)
+    sol = tdgl.solve(device, tdgl.SolverOptions(**kw, output_file="run/out.h5"), applied_vector_potential=1.0,
+                     terminal_currents=cur)
+    assert sol.path.endswith("run/out.h5") and len(sol.saved_steps) == 1
+    f = rec.OPENED[sol.path]
+    tmp = rec.OPENED[sol.path + ".tmp"]
+    assert f.closed and tmp.closed
+    assert set(f) == {"mesh", "data", "applied_vector_potential", "epsilon", "solution"}
+    assert list(f["data"]) == [str(k) for k in range(len(mem.saved_steps))]
+    assert [(int(f[f"data/{k}"].attrs["step"])) for k in range(len(mem.saved_steps))] == [s.step for s in mem.saved_steps]
+    every = kw["save_every"]
+    for k, s in enumerate(mem.saved_steps):
+        g = f[f"data/{k}"]
+        assert g.attrs["time"] == s.time and g.attrs["dt"] == s.dt
+        for name in ("psi", "mu", "supercurrent", "normal_current"):
+            assert np.array_equal(g[name].value, getattr(s, name)), (k, name)
+        assert g["induced_vector_potential"].shape == (len(s.supercurrent), 2)
+        if k == 0:
+            assert "running_state" not in g
+            continue
+        lo = mem.saved_steps[k - 1].step
+        hi = min(s.step + (1 if s.step % every else 0), len(mem.dynamics.dt))
+        want = np.zeros(every)
+        want[: hi - lo] = mem.dynamics.dt[lo:hi]
+        assert np.array_equal(g["running_state/dt"].value, want), k
+        assert np.array_equal(g["running_state/mu"].value[:, : hi - lo], mem.dynamics.mu[:, lo:hi])
+    # the solution group the reference's Solution.from_hdf5 starts from
+    sg = f["solution"]
+    assert sg["options"].attrs["save_every"] == every and sg.attrs["current_units"] == "uA"
+    assert set(sg["device"]) >= {"layer", "film", "terminals", "probe_points", "mesh"}
+    assert sg["device/layer"].attrs["coherence_length"] == 0.5 and "terminal_currents.pickle" in sg
+    # latest-step file: one group, last saved state
+    assert set(tmp["data"]) == {"-1"} and tmp["data/-1/step"][0] == mem.saved_steps[-1].step
+    # a run that dies after some saves leaves them on disk, files closed
+    solver = tdgl.TDGLSolver(device, tdgl.SolverOptions(**kw, output_file="run/dies.h5"),
+                             applied_vector_potential=1.0, terminal_currents=cur)
+    real_run, calls = solver.ctx.run, []
+
+    def flaky(*a, **k):
+        calls.append(1)
+        if len(calls) > 8:
+            raise RuntimeError("boom")
+        return real_run(*a, **k)
+
+    solver.ctx.run = flaky
+    with pytest.raises(RuntimeError, match="boom"):
+        solver.solve()
+    died = [v for p, v in rec.OPENED.items() if p.endswith("run/dies.h5")][0]
+    assert died.closed and len(list(died["data"])) >= 2 and "solution" not in died

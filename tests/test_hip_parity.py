@@ -438,6 +438,42 @@ def test_trajectory_transport_with_terminals_and_thermalisation():
         assert abs(total - cur) < 1e-8 * cur
 
 
+def test_trajectory_transport_on_the_polygon_device_with_holes():
+    """SURVEY 8(f) rank 1 on the HIP path: the reference's own test device shape
+    (tdgl/test/conftest.py:7-49: 10x10 box united with a 30x4 strip, two round holes, current
+    terminals on the strip ends, probes on the strip) on the constrained-Delaunay mesh of fixture
+    mesh_polygon -- 791 reference steps with thermalisation, vortices pinned by / moving past the
+    holes."""
+    g = load_golden("traj_transport_polygon")
+    mesh = reference_mesh(load_golden("mesh_polygon"))
+    terms = [edge_terminal(mesh, "source", -15.0), edge_terminal(mesh, "drain", 15.0)]
+    cur = float(g["current"])
+    solver = _hip_solver(g, mesh, float(g["b"]), terminals=terms, current_func={"source": cur, "drain": -cur})
+    sol = solver.solve()
+    n_sim = int((g["call_time"] == 0).nonzero()[0][-1])
+    assert sol.stats["steps_thermalizing"] == n_sim
+    _assert_hip_trajectory(g, sol, 1e-7, n_sim=n_sim)
+    assert np.all(sol.tdgl_data.psi[g["fixed_sites"]] == 0)
+    # the injected current crosses every vertical cut, also the ones through the holes
+    em = mesh.edge_mesh
+    d = sol.tdgl_data
+    for x0 in (-12.3, -6.1, -2.4, 0.2, 2.7, 9.9):
+        xa, xb = mesh.sites[em.edges[:, 0], 0], mesh.sites[em.edges[:, 1], 0]
+        cross = (xa < x0) != (xb < x0)
+        sign = np.where(xa < x0, 1.0, -1.0)
+        total = ((d.supercurrent + d.normal_current) * em.dual_edge_lengths * sign)[cross].sum()
+        assert abs(total - cur) < 1e-8 * cur
+
+
+def test_trajectory_on_a_smoothed_non_delaunay_mesh():
+    """Laplacian-smoothed mesh (reference: Mesh.smooth, finite_volume/mesh.py:245-283): circumcentres
+    leave their triangles and the cells take the reference's convex-hull areas (util.py:169-255)."""
+    g = load_golden("traj_irregular_smoothed")
+    mesh = reference_mesh(load_golden("mesh_irregular_smoothed"))
+    sol = _hip_solver(g, mesh, float(g["b"])).solve()
+    _assert_hip_trajectory(g, sol, 1e-7)
+
+
 def test_trajectory_time_dependent_current_free_terminal_psi():
     g = load_golden("traj_transport_ramp")
     mesh = reference_mesh(load_golden("mesh_strip"))
@@ -698,7 +734,8 @@ def _oracle_states(g, mesh, b, steps, terminals=(), current_func=None):
     return rec
 
 
-@pytest.mark.parametrize("case", ["traj_field_small", "traj_transport_strip", "traj_transport_ramp", "traj_retry_small"])
+@pytest.mark.parametrize("case", ["traj_field_small", "traj_transport_strip", "traj_transport_ramp", "traj_retry_small",
+                                  "traj_transport_polygon", "traj_irregular_smoothed"])
 def test_teacher_forced_steps(case):
     """Per-step parity without trajectory amplification: start the HIP step from the oracle's
     state at step k and compare one step later (psi update incl. retries, Poisson solve,
@@ -706,7 +743,13 @@ def test_teacher_forced_steps(case):
     g = load_golden(case)
     b = float(g["b"])
     terms, cf = (), None
-    if "transport" in case:
+    if case == "traj_transport_polygon":
+        mesh = reference_mesh(load_golden("mesh_polygon"))
+        terms = [edge_terminal(mesh, "source", -15.0), edge_terminal(mesh, "drain", 15.0)]
+        cf = {"source": float(g["current"]), "drain": -float(g["current"])}
+    elif case == "traj_irregular_smoothed":
+        mesh = reference_mesh(load_golden("mesh_irregular_smoothed"))
+    elif "transport" in case:
         mesh = reference_mesh(load_golden("mesh_strip"))
         terms = [edge_terminal(mesh, "source", -30.0), edge_terminal(mesh, "drain", 30.0)]
         if "ramp" in case:
@@ -743,3 +786,60 @@ def test_teacher_forced_steps(case):
         worst = max(worst, dev)
         assert dev < 1e-9, (case, k, dev)
     print(f"{case}: worst one-step deviation over {len(steps)} steps = {worst:.2e}")
+
+
+def test_tabulated_currents_and_epsilon_run_inside_the_time_loop():
+    """Time-dependent terminal currents as piecewise-linear tables (TabulatedCurrents) and a
+    separable disorder parameter factor(t) * static(r) (SeparableEpsilon) are uploaded once and
+    evaluated by tdgl_run itself: whole save_every batches per call instead of one Python round trip
+    per step -- the same trajectory as the per-step callables (reference path: update_mu_boundary,
+    solver.py:325-345; update_epsilon, :364-381), and the current ramp still follows the reference
+    fixture traj_transport_ramp."""
+    from tdgl_amd import SolverOptions, TDGLSolver
+    from tdgl_amd.parameter import PiecewiseLinear, SeparableEpsilon, TabulatedCurrents
+
+    g = load_golden("traj_transport_ramp")
+    mesh = reference_mesh(load_golden("mesh_strip"))
+    terms = [edge_terminal(mesh, "source", -30.0), edge_terminal(mesh, "drain", 30.0)]
+    ramp = lambda t: {"source": 0.5 * min(t, 8.0), "drain": -0.5 * min(t, 8.0)}  # noqa: E731
+    table = TabulatedCurrents([0.0, 8.0, 1e9], dict(source=[0.0, 4.0, 4.0], drain=[0.0, -4.0, -4.0]))
+    assert table(3.0) == ramp(3.0) and table(11.0) == ramp(11.0)
+    runs = {}
+    for name, cf in (("callable", ramp), ("table", table)):
+        solver = _hip_solver(g, mesh, 0.0, terminals=terms, current_func=cf)
+        calls = []
+        real = solver.ctx.run
+        solver.ctx.run = lambda *a, _r=real, **k: (calls.append(a[0]), _r(*a, **k))[1]
+        runs[name] = (solver.solve(), calls)
+        assert solver._currents_on_device == (name == "table")
+    (s_c, calls_c), (s_t, calls_t) = runs["callable"], runs["table"]
+    assert max(calls_c) == 1 and max(calls_t) == int(g["opt_save_every"]) and len(calls_t) < len(calls_c) / 20
+    assert len(s_t.dynamics.dt) == len(s_c.dynamics.dt)
+    # the same arithmetic up to the interpolation's rounding; the run sits at the stability edge of the
+    # scheme (see test_trajectory_time_dependent_current_free_terminal_psi), so: first 65 steps
+    assert max_abs(s_t.dynamics.dt[:65], s_c.dynamics.dt[:65]) <= 1e-6 * s_c.dynamics.dt.max()
+    assert max_abs(s_t.dynamics.dt[:65], g["call_dt"][:65]) <= 1e-6 * g["call_dt"].max()
+    assert [s.step for s in s_t.saved_steps] == list(g["save_step"])
+
+    # separable epsilon: a hot stripe switched on over time
+    small = reference_mesh(load_golden("mesh_small"))
+    static = np.where(np.abs(small.sites[:, 0]) < 2.0, 1.0, 0.4)
+    factor = PiecewiseLinear([0.0, 1.0, 2.0], [1.0, 0.2, 0.9])
+    eps = SeparableEpsilon(static, factor)
+    opts = SolverOptions(solve_time=3.0, dt_init=1e-3, save_every=50, pcg_rtol=1e-11)
+    out = {}
+    for name in ("callable", "table"):
+        kw = dict(epsilon_func=(lambda t: factor(t) * static)) if name == "callable" else {}
+        solver = TDGLSolver.from_dimensionless(small, opts, uniform_field_A(small, 0.3), static * factor(0.0), **kw)
+        if name == "table":
+            solver._eps_table = (static, factor.times, factor.values)
+            solver.epsilon_func, solver.dynamic_epsilon = (lambda t: factor(t) * static), True
+            solver.ctx.set_epsilon_table(static, factor.times, factor.values)
+            solver._epsilon_on_device = True
+        out[name] = solver.solve()
+    a, b = out["callable"], out["table"]
+    assert len(a.dynamics.dt) == len(b.dynamics.dt)
+    assert max_abs(a.dynamics.dt, b.dynamics.dt) <= 1e-9 * a.dynamics.dt.max()
+    assert max_abs(np.abs(a.tdgl_data.psi) ** 2, np.abs(b.tdgl_data.psi) ** 2) < 1e-8
+    assert max_abs(a.tdgl_data.epsilon, b.tdgl_data.epsilon) < 1e-12
+    assert eps(small.sites, t=1.5).shape == (len(small.sites),)

@@ -469,3 +469,58 @@ def test_gram_solve_of_the_projection_guess():
     bad = np.zeros((2, 2))
     c = np.zeros(2)
     assert lib.tdgl_host_solve_gram(2, f(bad), f(np.ones(2)), c.ctypes.data_as(C.POINTER(C.c_double))) != 0
+
+
+def test_data_handler_streams_the_reference_layout(tmp_path, monkeypatch):
+    """`tdgl_amd.io.DataHandler` driven the way the reference's Runner drives its DataHandler
+    (runner.py:362-368, 398-401, 452-453), against an in-memory recorder of every h5py call: group /
+    dataset / attribute names, the zero-padded running-state buffers, the in-place `data/-1` of the
+    latest-step `.tmp` file, renaming instead of overwriting, and the tmp file's removal."""
+    import h5_recorder as rec
+    from tdgl_amd.io import DataHandler, RunningState
+
+    monkeypatch.chdir(tmp_path)
+    rec.OPENED.clear()
+    mesh = synthetic_mesh(6)
+    n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
+    rng = np.random.default_rng(0)
+    save_every, n_steps = 4, 10  # saves at steps 0, 4, 8 and the partial one at the end (step 10)
+    running = RunningState({"dt": 1, "mu": 2, "theta": 2}, save_every)
+    dts = 0.1 + 0.01 * np.arange(n_steps + 1)
+    mu_p, th_p = rng.normal(size=(n_steps + 1, 2)), rng.normal(size=(n_steps + 1, 2))
+    (tmp_path / "out.h5").write_bytes(b"taken")  # an existing file is never overwritten
+    fields_at = {}
+    with DataHandler("out.h5", file_factory=rec.RecorderFile) as h:
+        assert h.output_path.endswith("out-1.h5") and h.tmp_path.endswith("out-1.h5.tmp")
+        h.save_mesh(mesh)
+        h.save_fixed_values({"applied_vector_potential": np.ones((m, 2)), "epsilon": np.ones(n)})
+        t = 0.0
+        for i in range(n_steps + 1):
+            state = dict(step=i, time=t, dt=float(dts[i]))
+            if i % save_every == 0:
+                fields_at[i] = dict(psi=rng.normal(size=n) + 1j, mu=rng.normal(size=n), supercurrent=rng.normal(size=m),
+                                    normal_current=rng.normal(size=m), induced_vector_potential=np.zeros((m, 2)))
+                h.save_time_step(state, fields_at[i], None if i == 0 else running.export())
+                running.clear()
+            running.extend({"dt": dts[i:i + 1], "mu": mu_p[i:i + 1], "theta": th_p[i:i + 1]})
+            t += dts[i]
+        # the loop ended at i = n_steps (not a multiple of save_every): one more save, runner.py:452-453
+        fields_at["end"] = dict(fields_at[8], psi=fields_at[8]["psi"] * 2)
+        h.save_time_step(dict(step=n_steps, time=t, dt=float(dts[-1])), fields_at["end"], running.export())
+        tmp, out = h.tmp_file, h.output_file
+        assert tmp.kw == {"libver": "latest"}
+        # the latest-step file holds ONE group, overwritten in place and flushed per dataset
+        assert set(tmp["data"]) == {"-1"} and tmp["data/-1/step"][0] == n_steps
+        assert np.array_equal(tmp["data/-1/psi"].value, fields_at["end"]["psi"]) and tmp["data/-1/psi"].flushes == 4
+    assert out.closed and tmp.closed and not os.path.exists(h.tmp_path)
+    assert set(out) == {"mesh", "data", "applied_vector_potential", "epsilon"} and out["data"].track_order
+    assert list(out["data"]) == ["0", "1", "2", "3"]
+    g0, g2, g3 = out["data/0"], out["data/2"], out["data/3"]
+    assert "running_state" not in g0 and set(g0.attrs) == {"timestamp", "step", "time", "dt"}
+    assert set(g2) == {"psi", "mu", "supercurrent", "normal_current", "induced_vector_potential", "running_state"}
+    assert g2.attrs["step"] == 8 and np.array_equal(g2["psi"].value, fields_at[8]["psi"])
+    assert np.array_equal(g2["running_state/dt"].value, dts[4:8]) and g2["running_state/dt"].shape == (4,)
+    assert np.array_equal(g2["running_state/mu"].value, mu_p[4:8].T)
+    # the final partial save: steps 8, 9, 10 and a zero column
+    assert np.array_equal(g3["running_state/dt"].value, np.concatenate([dts[8:11], [0.0]]))
+    assert np.array_equal(g3["running_state/theta"].value[:, :3], th_p[8:11].T) and g3.attrs["step"] == n_steps

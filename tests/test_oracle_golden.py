@@ -202,6 +202,36 @@ def test_trajectory_transport_with_terminals_and_thermalisation():
     assert np.all(out["psi"][g["fixed_sites"]] == 0)
 
 
+def test_trajectory_transport_on_the_polygon_device_with_holes():
+    """The reference's own test device shape (tdgl/test/conftest.py:7-49: box united with a strip,
+    two holes, terminals on the strip ends) on the constrained-Delaunay mesh of fixture mesh_polygon."""
+    g = load_golden("traj_transport_polygon")
+    mesh = reference_mesh(load_golden("mesh_polygon"))
+    terms = [edge_terminal(mesh, "source", -15.0), edge_terminal(mesh, "drain", 15.0)]
+    for t in terms:
+        assert np.array_equal(t["site_indices"], g[f"term_{t['name']}_sites"])
+        assert np.array_equal(t["boundary_edge_indices"], g[f"term_{t['name']}_boundary_pos"])
+    cur = float(g["current"])
+    solver, out = _run_case(g, mesh, float(g["b"]), terminals=terms,
+                            current_func=lambda t: {"source": cur, "drain": -cur})
+    assert max_abs(solver.mu_boundary, g["mu_boundary"]) < 1e-15
+    n_sim = int((g["call_time"] == 0).nonzero()[0][-1])  # thermalisation steps are taken but not logged
+    sim = {k: (v[n_sim:] if k.startswith("call_") else v) for k, v in g.items()}
+    assert out["book"]["calls"] == len(g["call_dt"])
+    out["book"]["calls"] = len(sim["call_dt"])
+    _assert_trajectory(sim, mesh, out, 1e-11)
+    assert np.all(out["psi"][g["fixed_sites"]] == 0)
+
+
+def test_trajectory_on_a_smoothed_non_delaunay_mesh():
+    """Laplacian-smoothed mesh: circumcentres leave their triangles, boundary cells take the
+    reference's convex-hull areas (tdgl/finite_volume/util.py:169-255)."""
+    g = load_golden("traj_irregular_smoothed")
+    mesh = reference_mesh(load_golden("mesh_irregular_smoothed"))
+    _, out = _run_case(g, mesh, float(g["b"]))
+    _assert_trajectory(g, mesh, out, 1e-11)
+
+
 def test_trajectory_time_dependent_current_free_terminal_psi():
     g = load_golden("traj_transport_ramp")
     mesh = reference_mesh(load_golden("mesh_strip"))
