@@ -333,6 +333,19 @@ def gen_device_meshes():
     save("traj_transport_polygon", b=0.15, current=1.0, probe_points=np.array(probes), fixed_sites=fx,
          mu_boundary=s.mu_boundary, **term_arrays, **options_arrays(o), **out)
 
+    # The adaptive run above is chaotic on this coarse mesh (the controller bounces dt between 0.005 and
+    # 0.03: a 1e-14 perturbation of psi_0 changes the reference's OWN dt sequence by O(1),
+    # tests/test_sensitivity.py), so it pins single steps, not the whole trajectory.  The same device
+    # with a fixed time step is stable (1e-14 -> 5e-11): stronger field, flux enters the holes.
+    o = SolverOptions(solve_time=4.0, skip_time=0.5, dt_init=5e-3, dt_max=5e-3, adaptive=False, save_every=100)
+    s, psi0, fx = make_ref_solver(poly, uniform_field_A(poly, 0.3), o, terminals=terms, currents=cur,
+                                  probe_points=probes)
+    out = run_reference(s, psi0, o, snapshot_steps=(10, 400))
+    print("transport_polygon_fixed_dt calls:", len(out["call_dt"]), "V", out["call_mu_probe"][-1],
+          "max|Js|", np.abs(out["final_supercurrent"]).max())
+    save("traj_transport_polygon_fixed_dt", b=0.3, current=1.0, probe_points=np.array(probes), fixed_sites=fx,
+         mu_boundary=s.mu_boundary, **term_arrays, **options_arrays(o), **out)
+
     gs = load("mesh_irregular_smoothed")
     sm = RefMesh.from_triangulation(gs["mesh_sites"], gs["mesh_elements"])
     assert np.allclose(sm.areas, gs["mesh_areas"], rtol=0, atol=0)

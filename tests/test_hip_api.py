@@ -207,7 +207,8 @@ def test_output_file_is_streamed_in_the_reference_layout(tmp_path, monkeypatch):
 
     def flaky(*a, **k):
         calls.append(1)
-        if len(calls) > 8:
+        written = [v for p, v in rec.OPENED.items() if p.endswith("run/dies.h5")]
+        if written and len(list(written[0]["data"])) >= 1:  # something has been saved: now die
             raise RuntimeError("boom")
         return real_run(*a, **k)
 
@@ -215,4 +216,4 @@ def test_output_file_is_streamed_in_the_reference_layout(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="boom"):
         solver.solve()
     died = [v for p, v in rec.OPENED.items() if p.endswith("run/dies.h5")][0]
-    assert died.closed and len(list(died["data"])) >= 2 and "solution" not in died
+    assert died.closed and len(list(died["data"])) >= 1 and "solution" not in died

@@ -451,12 +451,30 @@ def test_trajectory_transport_on_the_polygon_device_with_holes():
     solver = _hip_solver(g, mesh, float(g["b"]), terminals=terms, current_func={"source": cur, "drain": -cur})
     sol = solver.solve()
     n_sim = int((g["call_time"] == 0).nonzero()[0][-1])
-    assert sol.stats["steps_thermalizing"] == n_sim
-    _assert_hip_trajectory(g, sol, 1e-7, n_sim=n_sim)
+    # The adaptive controller bounces dt between 0.005 and 0.03 on this coarse mesh and the run is
+    # chaotic: the reference's OWN dt sequence changes by O(1) under a 1e-14 perturbation of psi_0
+    # (tests/test_sensitivity.py; measured here: first deviation above 1e-7 at step 76, inside the
+    # thermalisation stage).  So this run is checked for what must hold on ANY trajectory, single
+    # steps along the reference's trajectory are compared in test_teacher_forced_steps (1e-9), and
+    # the whole trajectory on the fixed-dt twin of this fixture below.
+    assert abs(sol.stats["steps_thermalizing"] - n_sim) <= 0.2 * n_sim
+    assert [s.step % int(g["opt_save_every"]) for s in sol.saved_steps[:-1]] == [0] * (len(sol.saved_steps) - 1)
     assert np.all(sol.tdgl_data.psi[g["fixed_sites"]] == 0)
+    _conserved_through_cuts(mesh, sol.tdgl_data, cur)
+
+    gf = load_golden("traj_transport_polygon_fixed_dt")
+    solver = _hip_solver(gf, mesh, float(gf["b"]), terminals=terms, current_func={"source": cur, "drain": -cur})
+    sol = solver.solve()
+    n_sim = int((gf["call_time"] == 0).nonzero()[0][-1])
+    assert sol.stats["steps_thermalizing"] == n_sim
+    _assert_hip_trajectory(gf, sol, 1e-8, n_sim=n_sim)
+    assert np.abs(sol.tdgl_data.supercurrent).max() > 1.0  # strong screening currents around the holes
+    _conserved_through_cuts(mesh, sol.tdgl_data, cur)
+
+
+def _conserved_through_cuts(mesh, d, cur):
     # the injected current crosses every vertical cut, also the ones through the holes
     em = mesh.edge_mesh
-    d = sol.tdgl_data
     for x0 in (-12.3, -6.1, -2.4, 0.2, 2.7, 9.9):
         xa, xb = mesh.sites[em.edges[:, 0], 0], mesh.sites[em.edges[:, 1], 0]
         cross = (xa < x0) != (xb < x0)

@@ -223,6 +223,20 @@ def test_trajectory_transport_on_the_polygon_device_with_holes():
     assert np.all(out["psi"][g["fixed_sites"]] == 0)
 
 
+def test_trajectory_transport_on_the_polygon_device_fixed_dt():
+    """The same device with a fixed time step: a stable trajectory (903 steps, flux in the holes)."""
+    g = load_golden("traj_transport_polygon_fixed_dt")
+    mesh = reference_mesh(load_golden("mesh_polygon"))
+    terms = [edge_terminal(mesh, "source", -15.0), edge_terminal(mesh, "drain", 15.0)]
+    cur = float(g["current"])
+    solver, out = _run_case(g, mesh, float(g["b"]), terminals=terms,
+                            current_func=lambda t: {"source": cur, "drain": -cur})
+    n_sim = int((g["call_time"] == 0).nonzero()[0][-1])
+    sim = {k: (v[n_sim:] if k.startswith("call_") else v) for k, v in g.items()}
+    out["book"]["calls"] = len(sim["call_dt"])
+    _assert_trajectory(sim, mesh, out, 1e-11)
+
+
 def test_trajectory_on_a_smoothed_non_delaunay_mesh():
     """Laplacian-smoothed mesh: circumcentres leave their triangles, boundary cells take the
     reference's convex-hull areas (tdgl/finite_volume/util.py:169-255)."""
