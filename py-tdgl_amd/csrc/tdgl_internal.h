@@ -160,6 +160,7 @@ struct tdgl_ctx {
     std::vector<int32_t> nbr_ranks, send_ptr, recv_ptr;
     tdgl::DevBuf<int32_t> d_send_idx;
     tdgl::DevBuf<double> d_sendbuf, d_gstat;
+    tdgl::DevBuf<float> d_red32;          // fp32 staging of the coarse right-hand side all-reduce
     double *h_sendbuf = nullptr, *h_recvbuf = nullptr;  // pinned (callback transport)
     int64_t h_buf_doubles = 0;
     bool fix_psi = true;
