@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtdgl_hip.so")
+# (TDGL_HIP_LIB: load another build of the library, e.g. a variant under measurement)
+LIB_PATH = os.environ.get("TDGL_HIP_LIB") or os.path.join(_HERE, "lib", "libtdgl_hip.so")
 
 TDGL_OK = 0
 TDGL_ERR_HIP = 1

@@ -48,6 +48,27 @@ def stdout_to_stderr():
         os.close(saved)
 
 
+def limit_host_threads(world: int) -> int:
+    """One process per GPU on ONE host: without this every rank's NumPy/SciPy (BLAS, OpenMP) and
+    torch open a thread per core, `world` times over -- measured on a 256-core box with 8 ranks
+    sharing it: 322 s of set-up and 25x slower host-side exchanges, against 1 s with 3 ranks.  Gives
+    each rank its share of the cores.  Returns the limit."""
+    n = max(1, (os.cpu_count() or 1) // max(1, int(world)))
+    try:
+        import threadpoolctl
+
+        threadpoolctl.threadpool_limits(limits=n)
+    except Exception:  # pragma: no cover - optional dependency
+        pass
+    try:
+        import torch
+
+        torch.set_num_threads(n)
+    except Exception:  # pragma: no cover
+        pass
+    return n
+
+
 def prepare_payloads(mesh, world, link_exponents, epsilon=1.0, **kw):
     """`prepare_payloads_for` all ranks."""
     return prepare_payloads_for(mesh, world, range(int(world)), link_exponents, epsilon, **kw)
@@ -74,6 +95,13 @@ def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, ter
         hierarchy = build_hierarchy(A_glob, max_coarse=max_coarse or min(600, max(8, n // 4)))
     coarse = dict(levels=list(hierarchy.levels[1:]), coarse_pinv=hierarchy.coarse_pinv,
                   sizes=hierarchy.sizes, operator_complexity=hierarchy.operator_complexity)
+    # the collapsed coarse chain involves only the replicated levels: built once here for the default
+    # smoother settings, not once per rank (`TDGLContext._refresh_collapsed` falls back to building
+    # it when the options differ)
+    from .amg import collapsed_operators
+
+    coarse["plan_key"] = (2, 1, 0.1, True, 2)  # nu, smoother (chebyshev), cheb_lo, collapse, tail_cycles
+    coarse["plan"] = collapsed_operators(hierarchy, 2, "chebyshev", 0.1, tail_cycles=2)
     A_e = np.asarray(link_exponents, dtype=float)
     eps = np.asarray(epsilon, dtype=float) * np.ones(n)
     mu_b = np.zeros(len(em.boundary_edge_indices)) if mu_boundary is None else np.asarray(mu_boundary, dtype=float)
@@ -129,6 +157,8 @@ class DistributedTDGL:
 
         self.dist = dist
         self.rank, self.world = int(rank), int(world)
+        if self.world > 1:
+            limit_host_threads(self.world)
         self.mesh = mesh
         self.options = options
         options.validate()

@@ -122,6 +122,7 @@ class TDGLContext:
         k = self._keep
         A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
         h = build_hierarchy(A, max_coarse=max_coarse)
+        self._shipped_plan = None
         self.set_hierarchy(h)
         self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step,
                                  smoother, cheb_lo, extrapolate, nu_fine)
@@ -213,6 +214,7 @@ class TDGLContext:
         lv0 = Level(A=loc["A"], dinv=loc["dinv"], rho=loc["rho"], P=loc["P"], R=loc["R"])
         hh = Hierarchy(levels=[lv0] + list(h.levels[1:]), coarse_pinv=h.coarse_pinv)
         self._local_level0 = lv0
+        self._shipped_plan = None
         self.set_hierarchy(hh, n_cols0=lp.n_loc)
         self.hierarchy = h
 
@@ -225,6 +227,7 @@ class TDGLContext:
         lv0 = Level(A=level0["A"], dinv=level0["dinv"], rho=level0["rho"], P=level0["P"], R=level0["R"])
         hh = Hierarchy(levels=[lv0] + list(coarse["levels"]), coarse_pinv=coarse["coarse_pinv"])
         self._local_level0 = lv0
+        self._shipped_plan = (coarse.get("plan_key"), coarse.get("plan")) if "plan" in coarse else None
         self.set_hierarchy(hh, n_cols0=lp.n_loc)
         self.hierarchy = _HierarchyInfo(hh, coarse.get("sizes"), coarse.get("operator_complexity"))
 
@@ -314,8 +317,13 @@ class TDGLContext:
         from .amg import collapsed_operators
 
         name = "jacobi" if o["smoother"] == 0 else "chebyshev"
-        plan = collapsed_operators(h, o["nu"], name, o["cheb_lo"], tail_cycles=o.get("tail_cycles", 2)) \
-            if (o.get("collapse", True) and o["nu"] == 2) else None
+        shipped = getattr(self, "_shipped_plan", None)
+        if shipped is not None and shipped[0] == (o["nu"], o["smoother"], o["cheb_lo"], o.get("collapse", True),
+                                                   o.get("tail_cycles", 2)):
+            plan = shipped[1]  # built once by the root rank (distributed.prepare_payloads)
+        else:
+            plan = collapsed_operators(h, o["nu"], name, o["cheb_lo"], tail_cycles=o.get("tail_cycles", 2)) \
+                if (o.get("collapse", True) and o["nu"] == 2) else None
         self.collapsed_plan = plan
         for k in range(1, len(h.levels) - 1):
             M = None if plan is None else plan["mid"].get(k)
