@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
                     help="also run BASELINE config 5 (4M-site film, same decomposition) and report it as `config5`; "
                          "auto = when more than one GPU is used")
+    ap.add_argument("--config5-timeout", type=int, default=900,
+                    help="seconds config 5 may take before the headline line is printed without it")
     ap.add_argument("--trace-iterations", default=None,
                     help="write dt / PCG iterations of every step (pre-roll included) to this .json file")
     ap.add_argument("--timeout", type=int, default=1500,
@@ -430,32 +432,10 @@ def main():
             traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
             algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=main_run.axp[0],
         )
-    # BASELINE config 5 next to the headline workload (decomposed runs)
-    config5 = None
-    want5 = args.config5 == "on" or (args.config5 == "auto" and world > 1)
-    if want5 and args.workload != "4M":
-        start_state_keep, wl_keep = main_run.start_state, main_run.wl
-        if main_run.drun is not None:
-            main_run.drun.close()
-        else:
-            main_run.ctx.close()
-        r5 = run_workload("4M", want_cpu_state=False)
-        if rank == 0:
-            l5 = line_for(r5)
-            config5 = dict(workload=f"{WORKLOADS['4M'][1]}, same options and decomposition (BASELINE config 5)",
-                           scaling="strong", **l5)
-        main_run.start_state, main_run.wl = start_state_keep, wl_keep
-
-    if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
     r = main_run
     desc = WORKLOADS[args.workload][1]
     strip = isinstance(WORKLOADS[args.workload][0], tuple)
-    out = dict(
+    out = None if rank != 0 else dict(
         metric=METRIC,
         value=main_line["value"],
         unit="steps/s",
@@ -483,10 +463,45 @@ def main():
         pcg=main_line["pcg"],
         step_aggregate=main_line["step_aggregate"],
     )
-    if "comm_per_step" in main_line:
+    if rank == 0 and "comm_per_step" in main_line:
         out["comm_per_step"] = main_line["comm_per_step"]
-    if config5 is not None:
-        out["config5"] = config5
+    # BASELINE config 5 next to the headline workload (decomposed runs).  The headline measurement is
+    # complete at this point: a watchdog thread prints it if the second workload does not finish in
+    # time (a hung collective blocks inside the library, where no Python signal handler runs), so the
+    # driver gets its line either way.
+    want5 = args.config5 == "on" or (args.config5 == "auto" and world > 1)
+    if want5 and args.workload != "4M":
+        import threading
+
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.config5_timeout) and rank == 0:
+                out["config5"] = dict(error=f"did not finish within {args.config5_timeout} s")
+                print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        start_state_keep, wl_keep = main_run.start_state, main_run.wl
+        try:
+            if main_run.drun is not None:
+                main_run.drun.close()
+            else:
+                main_run.ctx.close()
+            r5 = run_workload("4M", want_cpu_state=False)
+            if rank == 0:
+                out["config5"] = dict(workload=f"{WORKLOADS['4M'][1]}, same options and decomposition (BASELINE config 5)",
+                                      scaling="strong", **line_for(r5))
+        except Exception as exc:  # the headline line must still go out
+            if rank == 0:
+                out["config5"] = dict(error=f"{type(exc).__name__}: {exc}")
+        done.set()
+        main_run.start_state, main_run.wl = start_state_keep, wl_keep
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if r.start_state is not None:
         log("timing the CPU oracle (LU factorisation first; this takes a while at 1M sites)")
         wl = r.wl
