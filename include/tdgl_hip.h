@@ -164,7 +164,8 @@ int tdgl_poisson_set_fused_level(tdgl_ctx *ctx, int32_t level, const int32_t *ra
  *   - tdgl_poisson_set_collapsed_tail(t): everything from level t->level down.
  *       mode 0: e = G b, G = dense [n, n] (the cycle of that level formed explicitly, or the exact
  *               pseudo-inverse of its operator);
- *       mode 1: y = G b (G dense [g_rows, n]), e = W b + V y (W CSR [n, n], V dense [n, g_rows]).
+ *       mode 1: y = G b (G dense [g_rows, n]), e = W [b ; y] + V y[0 : v_cols] (W CSR over the
+ *               concatenated vector, [n, n + g_rows]; V dense [n, v_cols], v_cols may be 0).
  *     nu / smoother / cheb_lo are the smoother settings the operators were built for; the library
  *     falls back to the plain kernel sequence while tdgl_poisson_options differ.  t == NULL: off.
  * Replaced hierarchies drop both. */
@@ -174,7 +175,8 @@ typedef struct {
     const double *G;
     int64_t g_rows;                /* mode 1 */
     const int32_t *W_indptr;  const int32_t *W_indices;  const double *W_data;   /* mode 1 */
-    const double *V;               /* mode 1: dense row-major [n, g_rows] */
+    const double *V;               /* mode 1: dense row-major [n, v_cols] (NULL when v_cols = 0) */
+    int64_t v_cols;
     int32_t nu, smoother;
     double cheb_lo;
 } tdgl_collapsed_tail;

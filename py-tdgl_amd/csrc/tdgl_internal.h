@@ -246,13 +246,13 @@ struct tdgl_ctx {
     // down as explicit operators, built for the smoother settings (tail_nu, tail_smoother, tail_cheb_lo)
     int tail_level = -1;                  // -1: off
     int tail_mode = 0;                    // 0: e = B b (dense [n_t, n_t]);  1: y = G b, e = W b + V y
-    int64_t tail_g_rows = 0;              // rows of G = columns of V
+    int64_t tail_g_rows = 0;              // rows of G
+    int64_t tail_v_cols = 0;              // columns of the dense V (leading entries of G b)
     int64_t tail_ldg = 0, tail_ldv = 0;   // leading dimensions of G / V (padded to 4 entries)
     tdgl::DevBuf<double> tailG, tailV;    // dense row-major (mode 0: tailG holds B)
     tdgl::DevBuf<float> tailG32, tailV32;
     tdgl::Csr tailW;
     tdgl::DevBuf<uint16_t> tailW_idx16;   // its column indices in 16 bits (the tail level has < 65536 rows)
-    tdgl::DevBuf<double> tail_y;          // G b
     int tail_nu = 0, tail_smoother = 0;
     double tail_cheb_lo = 0.0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;

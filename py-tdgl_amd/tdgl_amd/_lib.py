@@ -121,6 +121,7 @@ class CollapsedTail(C.Structure):
         ("W_indices", c_i32p),
         ("W_data", c_f64p),
         ("V", c_f64p),
+        ("v_cols", C.c_int64),
         ("nu", C.c_int32),
         ("smoother", C.c_int32),
         ("cheb_lo", C.c_double),

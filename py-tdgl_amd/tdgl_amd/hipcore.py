@@ -344,7 +344,9 @@ class TDGLContext:
             W = plan["W"]
             keep = (f64(plan["G"]), i32(W.indptr), i32(W.indices), f64(W.data), f64(plan["V"]))
             t.mode, t.G, t.g_rows = 1, p_f64(keep[0]), keep[0].shape[0]
-            t.W_indptr, t.W_indices, t.W_data, t.V = p_i32(keep[1]), p_i32(keep[2]), p_f64(keep[3]), p_f64(keep[4])
+            t.W_indptr, t.W_indices, t.W_data = p_i32(keep[1]), p_i32(keep[2]), p_f64(keep[3])
+            t.v_cols = plan["V"].shape[1]
+            t.V = p_f64(keep[4]) if t.v_cols else None
         self._chk(lib.tdgl_poisson_set_collapsed_tail(ctx, C.byref(t)))
 
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
