@@ -339,6 +339,7 @@ def main():
         launches, k1_ms = ctx.profile_read()
         axp_launches, axp_ms = ctx.profile_read_pcg() if not use_dd else (0, 0.0)
         ctx.profile_enable(False)
+        ev_over = ctx.profile_event_overhead(50)  # (after the timed region)
         comm = ctx.comm_stats()
         if dist is not None:
             import torch
@@ -348,7 +349,7 @@ def main():
             elapsed = float(tmax.item())
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
-            k1=(launches, k1_ms), axp=(axp_launches, axp_ms), comm=comm, sizes=list(h.sizes), start_state=start_state,
+            k1=(launches, k1_ms), axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats()), overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
@@ -376,6 +377,9 @@ def main():
             traffic=traffic_of(table, "void tdgl::k_psi_laplacian<true"),
             traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
             algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"], avg_launch_ms=round(avg, 5), launches=launches,
+            # `achieved` uses the raw event readings; an empty event pair reads this much by itself
+            # (rocprofv3's dispatch durations in profiles/ do not contain it)
+            event_pair_overhead_ms=round(r.ev_over, 5),
         )
 
     def line_for(r):
@@ -431,6 +435,7 @@ def main():
             traffic=traffic_of(table, "void tdgl::k_sell_axp"),
             traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
             algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=main_run.axp[0],
+            event_pair_overhead_ms=round(main_run.ev_over, 5),
         )
     r = main_run
     desc = WORKLOADS[args.workload][1]

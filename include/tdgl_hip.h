@@ -411,6 +411,9 @@ int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
 /* The same for the kernel that dominates the run time, the CG's fused direction update + A p
  * (k_sell_axp): every 8th launch after tdgl_profile_enable is timed, up to 64 samples (single GPU). */
 int tdgl_profile_read_pcg(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
+/* Mean reading of an event pair with nothing recorded in between (the markers' own cost, which
+ * the in-run durations above contain and a profiler's dispatch durations do not). */
+int tdgl_profile_event_overhead(tdgl_ctx *ctx, int32_t reps, double *avg_ms);
 
 #ifdef __cplusplus
 }

@@ -1026,6 +1026,31 @@ extern "C" int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total
     return TDGL_OK;
 }
 
+// What an event pair reads with nothing between the two records: the marker packets' own
+// processing.  bench.py reports it next to the in-run kernel durations so that they can be
+// reconciled with rocprofv3's dispatch durations (which do not contain it).
+extern "C" int tdgl_profile_event_overhead(tdgl_ctx *ctx, int32_t reps, double *avg_ms) {
+    CTX_GUARD(ctx);
+    if (reps < 1 || !avg_ms) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_profile_event_overhead: reps >= 1 and avg_ms required");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        hipEvent_t e0, e1;
+        HIP_TRY(ctx, hipEventCreate(&e0));
+        HIP_TRY(ctx, hipEventCreate(&e1));
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    *avg_ms = total / reps;
+    return TDGL_OK;
+}
+
 extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms) {
     CTX_GUARD(ctx);
     if (!avg_ms || reps <= 0) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_time_kernel: bad arguments");

@@ -218,6 +218,7 @@ SIGNATURES = {
     "tdgl_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_profile_read_pcg": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
     "tdgl_profile_read": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
+    "tdgl_profile_event_overhead": (C.c_int, [_CTX, C.c_int32, c_f64p]),
 }
 
 _lib = None

@@ -652,6 +652,12 @@ class TDGLContext:
         self._chk(self._lib.tdgl_profile_read_pcg(self._ctx, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def profile_event_overhead(self, reps: int = 50) -> float:
+        """Mean reading (ms) of an event pair with nothing in between."""
+        ms = C.c_double(0)
+        self._chk(self._lib.tdgl_profile_event_overhead(self._ctx, int(reps), C.byref(ms)))
+        return ms.value
+
     def profile_read(self):
         n, ms = C.c_int64(0), C.c_double(0)
         self._chk(self._lib.tdgl_profile_read(self._ctx, C.byref(n), C.byref(ms)))
