@@ -13,7 +13,7 @@ from .parameter import (  # noqa: F401
     ConstantField, LinearRamp, Parameter, PiecewiseLinear, SeparableEpsilon, TabulatedCurrents,
 )
 from .options import SolverOptions, SolverOptionsError, SparseSolver  # noqa: F401
-from .solution import Solution  # noqa: F401
+from .solution import BiotSavartField, DynamicsData, Fluxoid, Solution, TDGLData  # noqa: F401
 from .solver import SolverResult, TDGLSolver, solve  # noqa: F401
 
 __version__ = "0.1.0"

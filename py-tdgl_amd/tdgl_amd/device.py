@@ -2,8 +2,8 @@
 
 Kept from the reference (`tdgl/device/device.py:49-566`, `layer.py:6-57`, `polygon.py:29-140`):
 constructor signatures, ``make_mesh``, ``terminal_info()``, probe points and the unit scales
-the solver needs.  Not kept: shapely polygon algebra, meshpy meshing of arbitrary polygons,
-HDF5 I/O and plotting (DESIGN.md "out of scope").
+the solver needs, ``to_hdf5`` / ``from_hdf5``.  Not kept: shapely polygon algebra (a native
+boundary-conforming mesher stands in for meshpy, `tdgl_amd.meshgen`) and plotting.
 
 Units.  The reference does unit conversion with ``pint`` (absent on the target image).  Only
 four conversions reach the solver, so they are written out with CODATA-2018 constants, the
@@ -88,6 +88,19 @@ class Layer:
         if self.conductivity is not None:
             h5_group.attrs["conductivity"] = self.conductivity
 
+    @staticmethod
+    def from_hdf5(h5_group) -> "Layer":
+        """`tdgl/device/layer.py:74-98`."""
+        get = lambda key: h5_group.attrs[key] if key in h5_group.attrs else None  # noqa: E731
+        kwargs = {k: get(k) for k in ("london_lambda", "coherence_length", "thickness", "conductivity", "u", "gamma", "z0")}
+        return Layer(**{k: (v if v is None else float(v)) for k, v in kwargs.items()})
+
+    def __eq__(self, other):
+        if not isinstance(other, Layer):
+            return False
+        keys = ("london_lambda", "coherence_length", "thickness", "conductivity", "u", "gamma", "z0")
+        return all(getattr(self, k) == getattr(other, k) for k in keys)
+
     def __repr__(self):
         return (
             f"Layer(london_lambda={self.london_lambda}, coherence_length={self.coherence_length},"
@@ -149,6 +162,23 @@ class Polygon:
             h5_group.attrs["name"] = self.name
         h5_group.attrs["mesh"] = self.mesh
         h5_group["points"] = self.points
+
+    @classmethod
+    def from_hdf5(cls, h5_group) -> "Polygon":
+        """`tdgl/device/polygon.py:588-598`."""
+        name = h5_group.attrs["name"] if "name" in h5_group.attrs else None
+        return cls(name=None if name is None else str(name), points=np.array(h5_group["points"]),
+                   mesh=bool(h5_group.attrs["mesh"]))
+
+    def __eq__(self, other) -> bool:
+        if other is self:
+            return True
+        if not isinstance(other, Polygon):
+            return False
+        return self.name == other.name and self.points.shape == other.points.shape and np.allclose(
+            self.points, other.points)
+
+    __hash__ = None
 
     @property
     def area(self) -> float:
@@ -269,6 +299,37 @@ class Device:
                 hole.to_hdf5(grp.create_group(hole.name))
         if save_mesh and self.mesh is not None:
             write_mesh(h5_group.create_group("mesh"), self.mesh)
+
+    @classmethod
+    def from_hdf5(cls, path_or_group) -> "Device":
+        """The inverse of :meth:`to_hdf5` (`tdgl/device/device.py:811-865`): a path (opened through
+        `tdgl_amd.io.open_h5`, i.e. h5py) or an open group."""
+        from .io import open_h5, read_mesh
+
+        if isinstance(path_or_group, (str, bytes)) or hasattr(path_or_group, "__fspath__"):
+            f = open_h5(path_or_group, "r")
+            try:
+                return cls.from_hdf5(f)
+            finally:
+                f.close()
+        f = path_or_group
+        if not hasattr(f, "attrs"):
+            raise TypeError(f"Expected an h5py.File or h5py.Group, but got {type(f)}.")
+        terminals = holes = probe_points = mesh = None
+        if "terminals" in f:
+            terminals = [Polygon.from_hdf5(f["terminals"][k]) for k in f["terminals"]]
+        if "holes" in f:
+            holes = [Polygon.from_hdf5(f["holes"][k]) for k in sorted(f["holes"])]
+        if "probe_points" in f:
+            probe_points = np.array(f["probe_points"])
+        if "mesh" in f:
+            mesh = read_mesh(f["mesh"])
+        device = cls(str(f.attrs["name"]), layer=Layer.from_hdf5(f["layer"]), film=Polygon.from_hdf5(f["film"]),
+                     holes=holes, terminals=terminals, probe_points=probe_points,
+                     length_units=str(f.attrs["length_units"]))
+        if mesh is not None:
+            device.mesh = mesh
+        return device
 
     # -- units and scales -----------------------------------------------------------------
     @property

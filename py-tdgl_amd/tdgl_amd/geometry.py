@@ -60,3 +60,18 @@ def close_curve(points: np.ndarray) -> np.ndarray:
     if not np.allclose(points[0], points[-1]):
         points = np.concatenate([points, points[:1]], axis=0)
     return points
+
+
+def unit_vector(vector: np.ndarray) -> np.ndarray:
+    """Rows of ``vector`` scaled to unit length (`tdgl/geometry.py:166-168`)."""
+    vector = np.asarray(vector, dtype=float)
+    return vector / np.linalg.norm(vector, axis=-1)[:, np.newaxis]
+
+
+def path_vectors(path: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Segment lengths [n-1] and unit normals [n-1, 2] of a path given by its n points
+    (`tdgl/geometry.py:171-185`): the normal of a segment d is d x z = (d_y, -d_x) / |d|, i.e. it
+    points to the right of the direction of travel."""
+    dr = np.diff(np.asarray(path, dtype=float), axis=0)
+    normals = np.stack([dr[:, 1], -dr[:, 0]], axis=1)
+    return np.linalg.norm(dr, axis=1), unit_vector(normals)

@@ -74,6 +74,21 @@ def _h5py_factory(path, mode, **kw):
     return _require_h5py().File(path, mode, **kw)
 
 
+def open_h5(path, mode="r"):
+    """Open an output file for reading through the same factory the writer uses (h5py by default)."""
+    return _h5py_factory(path, mode)
+
+
+def read_mesh(group):
+    """`Mesh.from_hdf5` (mesh.py:371-400) for the layout `write_mesh` produces: the dual mesh is
+    rebuilt from ``sites`` / ``elements``."""
+    from .finite_volume import Mesh
+
+    if not ("sites" in group and "elements" in group):
+        raise IOError("Could not load mesh due to missing data.")
+    return Mesh.from_triangulation(np.array(group["sites"]).squeeze(), np.array(group["elements"], dtype=np.int64))
+
+
 class DataHandler:
     """Streams the saved steps to disk in the reference's layout (`tdgl/solver/runner.py:24-183`).
 

@@ -95,6 +95,11 @@ class RecorderFile(Group):
         self.file_flushes = 0
         if mode == "x" and path in OPENED and not OPENED[path].closed:
             raise FileExistsError(path)
+        if mode == "x":  # like h5py, leave a file behind (readers check that it exists)
+            try:
+                open(path, "ab").close()
+            except OSError:
+                pass
         OPENED[path] = self
 
     def flush(self):
@@ -102,3 +107,12 @@ class RecorderFile(Group):
 
     def close(self):
         self.closed = True
+
+
+def open_file(path, mode="x", **kw):
+    """Factory with h5py.File's signature: "x" creates, "r" re-opens what was written to ``path``."""
+    if mode == "r":
+        f = OPENED[str(path)]
+        f.closed = False
+        return f
+    return RecorderFile(str(path), mode, **kw)
