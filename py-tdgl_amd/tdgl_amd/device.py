@@ -331,6 +331,29 @@ class Device:
             device.mesh = mesh
         return device
 
+    def __eq__(self, other) -> bool:
+        """Same description (`tdgl/device/device.py:885-915`): name, layer, film, holes, terminals,
+        probe points and length units; the mesh is not compared."""
+        if other is self:
+            return True
+        if not isinstance(other, Device):
+            return False
+
+        def same(seq1, seq2):
+            key = attrgetter("name")
+            return sorted(seq1, key=key) == sorted(seq2, key=key)
+
+        if self.probe_points is None or other.probe_points is None:
+            same_probes = self.probe_points is None and other.probe_points is None
+        else:
+            same_probes = self.probe_points.shape == other.probe_points.shape and np.allclose(
+                self.probe_points, other.probe_points)
+        return (self.name == other.name and self.layer == other.layer and self.film == other.film
+                and same(self.holes, other.holes) and same(list(self.terminals), list(other.terminals))
+                and same_probes and self.length_units == other.length_units)
+
+    __hash__ = None
+
     # -- units and scales -----------------------------------------------------------------
     @property
     def length_units(self) -> str:

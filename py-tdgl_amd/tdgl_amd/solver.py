@@ -450,9 +450,12 @@ class TDGLSolver:
         if self.seed_solution is None:
             psi0, mu0 = self.psi_init, self.mu_init
         else:
-            if self.seed_solution.device is not self.device:
+            if self.seed_solution.device != self.device:
                 raise ValueError("The seed_solution.device must be equal to the device being simulated.")
             seed = self.seed_solution.tdgl_data
+            if len(seed.psi) != len(self.device.mesh.sites):  # (equal devices may carry different meshes)
+                raise ValueError(
+                    f"The seed solution has {len(seed.psi)} sites, the device's mesh {len(self.device.mesh.sites)}.")
             psi0, mu0 = seed.psi, seed.mu
         ctx.set_state(psi0, mu0)
         if self.screening is not None:  # solver.py:738-745
