@@ -727,6 +727,40 @@ def test_strongly_irregular_mesh_matches_oracle():
     assert res["pcg_iters"].max() < 40
 
 
+@pytest.mark.parametrize("lx, ly", [(1.0, 1.0), (2.0, 1.0), (3.0, 2.0), (6.0, 4.0), (9.0, 7.0), (30.0, 21.0)])
+def test_very_small_meshes_match_oracle(lx, ly):
+    """Ragged and degenerate sizes: 5 to ~800 sites -- fewer rows than a wavefront, a single SELL slice,
+    a hierarchy that is only the dense coarsest level (<= 600 sites), a two-level one, a projection
+    window larger than what the mesh can tell apart.  Twenty adaptive steps against the oracle.  (The
+    oracle on such meshes answers a 1e-14 perturbation of psi_0 with up to 2e-10 after 20 steps and
+    3e-9 / 8e-6 after 30 / 40 steps in a stronger field: SuperLU's arbitrary constant in mu, -20 ... 0.5,
+    costs digits; some sizes -- 4 x 3, 5 x 3 -- it refuses as exactly singular, as the reference would.)"""
+    from oracle import OracleSolver, run_time_loop
+    from tdgl_amd import SolverOptions, TDGLSolver
+    from tdgl_amd.finite_volume import Mesh
+    from tdgl_amd.meshgen import hex_jitter_points, triangulate
+
+    pts = hex_jitter_points(lx, ly, pitch=1.0, jitter=0.05, seed=2)
+    mesh = Mesh.from_triangulation(pts, triangulate(pts))
+    n = len(mesh.sites)
+    assert 5 <= n < 900
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-3, dt_max=1e-1, save_every=10**9, pcg_rtol=1e-12)
+    A = uniform_field_A(mesh, 0.2)
+    solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0, U_DEFAULT, GAMMA_DEFAULT)
+    ctx = solver.ctx
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    res = ctx.run(20)
+    got = ctx.get_state()
+    want = run_time_loop(OracleSolver(mesh, A, 1.0, U_DEFAULT, GAMMA_DEFAULT, opts), opts, max_steps=20)
+    assert max_abs(res["dt"], want["log"].array("dt").ravel()) <= 1e-9 * res["dt"].max()
+    assert max_abs(got["psi"] * np.exp(-1j * np.angle(got["psi"][0])), want["psi"] * np.exp(-1j * np.angle(want["psi"][0]))) < 1e-8
+    scale = max(1.0, np.abs(remove_mean(want["mu"])).max())
+    assert max_abs(remove_mean(got["mu"]), remove_mean(want["mu"])) < 1e-8 * scale
+    assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-8
+    assert max_abs(got["normal_current"], want["normal_current"]) < 1e-8 * scale
+
+
 def _oracle_states(g, mesh, b, steps, terminals=(), current_func=None):
     """Run the oracle and record, for each k in `steps`, everything step k starts from and
     produces."""
