@@ -322,8 +322,19 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, ctx->js.alloc(ctx->m_pad));
     HIP_TRY(ctx, ctx->jn.alloc(ctx->m_pad));
     HIP_TRY(ctx, ctx->d_status.alloc(1));
-    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(StepStatus)));
+    // The status block is published into device memory and copied to this pinned block at every host
+    // synchronisation (a ~4 us blit kernel, twice per step).  TDGL_STATUS_MAPPED=1 lets the publishing
+    // workgroup store straight into the (mapped) host block instead: nothing at >= 250k sites, +10 % at
+    // 5.8k sites (profiles/AB_r02s.jsonl) -- not the default: one of ~40 runs with it ended in a core
+    // dump that could neither be reproduced nor explained.
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(StepStatus), hipHostMallocMapped));
     memset(ctx->h_status, 0, sizeof(StepStatus));
+    ctx->status_copy = getenv("TDGL_STATUS_MAPPED") == nullptr;
+    if (ctx->status_copy) {
+        ctx->status_dev = ctx->d_status.p;
+    } else {
+        HIP_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_dev), ctx->h_status, 0));
+    }
     HIP_TRY(ctx, ctx->scal.alloc(S_COUNT));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
@@ -453,7 +464,7 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
 // sets S_BB / S_TOL2, resets the iteration counters); rr_part: residual partials to sum into S_RR
 static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double *rr_part = nullptr) {
     const bool psi = ctx->psi_status_pending;
-    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->d_status.p, ctx->scal.p,
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->status_dev, ctx->scal.p,
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
                        ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
@@ -946,7 +957,8 @@ extern "C" int tdgl_psi_update(tdgl_ctx *ctx, const double *psi, const double *m
     launch_psi_update(ctx, s.c0.p, s.r0.p, lap.p, dt, pnew.p, s.r1.p);
     publish_status(ctx);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status.p, sizeof(StepStatus), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->status_copy)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status.p, sizeof(StepStatus), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *ok = ctx->h_status->fail_flag ? 0 : 1;
     TDGL_TRY(download_sites(ctx, pnew.p, reinterpret_cast<double2 *>(psi_out)));

@@ -290,7 +290,9 @@ struct tdgl_ctx {
     int psi_blocks = 0;                    // its grid
     bool psi_status_pending = false;       // not yet reduced into d_status
     tdgl::DevBuf<tdgl::StepStatus> d_status;
-    tdgl::StepStatus *h_status = nullptr;  // pinned
+    tdgl::StepStatus *h_status = nullptr;  // pinned, mapped into the device
+    tdgl::StepStatus *status_dev = nullptr;  // what the kernels write: h_status's device view (or d_status)
+    bool status_copy = false;
     std::vector<int32_t> probes;           // internal site ids
     tdgl::DevBuf<int32_t> d_probes;
     tdgl::DevBuf<double> d_probe_out;      // [2 * n_probe]
