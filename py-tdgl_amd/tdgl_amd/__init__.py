@@ -10,7 +10,8 @@ from .device import Device, Layer, Polygon, TerminalInfo  # noqa: F401
 from .finite_volume import EdgeMesh, Mesh  # noqa: F401
 from .operators import MeshOperators  # noqa: F401
 from .parameter import (  # noqa: F401
-    ConstantField, LinearRamp, Parameter, PiecewiseLinear, SeparableEpsilon, TabulatedCurrents,
+    CompositeParameter, Constant, ConstantField, LinearRamp, Parameter, PiecewiseLinear, Scale, SeparableEpsilon,
+    TabulatedCurrents,
 )
 from .options import SolverOptions, SolverOptionsError, SparseSolver  # noqa: F401
 from .solution import BiotSavartField, DynamicsData, Fluxoid, Solution, TDGLData  # noqa: F401

@@ -245,11 +245,78 @@ def test_parameter_arithmetic_and_separable_products():
         assert np.allclose(prod(x, y, z, t=0.0), 0.5 * field(x, y, z))
     assert (field + ramp * field).separable_product() is None       # not a pure product
     assert (field * 2.0).separable_product() is None                # nothing time dependent
-    moving = Parameter(lambda x, y, z, *, t: np.stack([x * t, y, z], axis=1))
+    moving = Parameter(lambda x, y, z, *, t: np.stack([x * t, y, z], axis=1), time_dependent=True)
     assert (ramp * moving).separable_product() is None              # the field itself moves
     assert np.allclose((2.0 * field - field)(x, y, z), field(x, y, z))
     with pytest.raises(ValueError, match="'t' cannot be bound"):
         Parameter(lambda x, y, z, *, t: x, t=1.0)
+    # the ramp is one number for all positions, as the reference's (sources/scaling.py:4-14)
+    assert ramp(x, y, z, t=2.0) == 1.0 and (ramp * field)(x, y, z, t=2.0).shape == (5, 3)
+
+
+def _gauss_2d(x, y, sigma=1):
+    return np.exp(-(x**2 + y**2) / (2 * sigma**2))
+
+
+def _gauss_3d(x, y, z, sigma=1):
+    return np.exp(-(x**2 + y**2 + z**2) / (2 * sigma**2))
+
+
+@pytest.mark.parametrize("func, nargs", [(_gauss_2d, 2), (_gauss_3d, 3)])
+def test_parameter_behaves_like_the_reference(func, nargs):
+    """The cases of the reference's own tests (tdgl/test/test_parameter.py): values, algebra incl. **,
+    equality by code and arguments, pickling, signature errors, repr."""
+    import pickle
+
+    import tdgl_amd as tdgl
+    from tdgl_amd.parameter import CompositeParameter, Constant, Parameter, Scale, function_repr
+
+    rng = np.random.default_rng(0)
+    args = tuple(rng.random(100) for _ in range(nargs))
+    p1, p2 = Parameter(func, sigma=10), Parameter(func, sigma=0.1)
+    f1, f2 = func(*args, sigma=10), func(*args, sigma=0.1)
+    assert np.array_equal(p1(*args), f1) and tdgl.Parameter is Parameter
+    for got, want in [
+        ((p1**2)(*args), f1**2), ((2 * p1)(*args), 2 * f1), ((1 + p1)(*args), 1 + f1), ((1 - p1)(*args), 1 - f1),
+        ((2**p1)(*args), 2**f1), ((1 / (10 + p1))(*args), 1 / (10 + f1)), ((p1 + p2)(*args), f1 + f2),
+        ((p1 - p2)(*args), f1 - f2), ((p1 * p2)(*args), f1 * f2), ((p1 / p2)(*args), f1 / f2), ((p1**p2)(*args), f1**f2),
+        ((-p1)(*args), -f1),
+    ]:
+        assert np.array_equal(got, want)
+    assert p1 == p1 and p1 != p2 and p1 == Parameter(func, sigma=10) and p1 != Parameter(_gauss_2d if nargs == 3 else _gauss_3d, sigma=10)
+    assert (p1 * p2) == (p1 * p2) and (p1**2) != p1 and (p1**2) != p1 * p2 and (p1 * p2) != (p1 / p2)
+    assert repr(p1) == f"Parameter<{func.__name__}(sigma=10)>"
+    assert repr(p1 * p2 + 2) == f"CompositeParameter<(({func.__name__}(sigma=10) * {func.__name__}(sigma=0.1)) + 2)>"
+    assert pickle.loads(pickle.dumps(p1)) == p1 and pickle.loads(pickle.dumps(p1)) != p2
+    assert pickle.loads(pickle.dumps(p1 * p2)) == (p1 * p2) and pickle.loads(pickle.dumps(p1 - p2)) != (p1 / p2)
+    assert p1(0.0, 0.0, *([0.0] if nargs == 3 else [])) == 1.0  # numbers in, a number out
+    with pytest.raises(TypeError):
+        CompositeParameter(1, 2, "+")
+    with pytest.raises(ValueError, match="Unknown operator"):
+        CompositeParameter(p1, p2, "<<")
+    assert CompositeParameter(p1, p2, " ** ") == p1**p2
+
+    def bad1(a, x, y, b=0): pass
+    def bad2(x, y, a, z): pass
+    def bad3(x, y, z, a): pass
+    def ok(x, y, a=0, b=0): pass
+    def timed(x, y, z, *, t, w=1.0): return np.cos(w * t) * np.ones_like(x)
+
+    for f, kw in [(bad1, dict(b=0)), (bad2, {}), (bad3, {}), (ok, dict(a=0, c=None))]:
+        with pytest.raises(ValueError):
+            Parameter(f, **kw)
+    with pytest.raises(ValueError, match="must take time t"):
+        Parameter(ok, time_dependent=True)
+    s = Scale(timed, w=2.0)
+    assert s.time_dependent and np.allclose(s(args[0], args[1], args[0], t=0.5), np.cos(1.0))
+    assert repr(s) == "Parameter<timed(time_dependent=True, w=2.0)>"
+    assert (s * p1).time_dependent and not (p1 * p2).time_dependent
+    assert np.array_equal(Constant(3.0)(args[0], args[1]), 3.0 * np.ones(100))
+    with pytest.raises(ValueError, match="Dimensions"):
+        Constant(1.0, dimensions=4)
+
+    def f(x, *, a: int, b: float, c=None): pass
+    assert function_repr(f) == "f(x, *, a: 'int', b: 'float', c=None)"
 
 
 # ---------------------------------------------------------------- HDF5 layout (no h5py needed)
