@@ -231,6 +231,8 @@ struct tdgl_ctx {
     tdgl::Csr fusedR;                     // R0 (I - c A0 D0^-1): restriction of the pre-smoothed residual
     double fusedR_c = 0.0;                // the smoothing coefficient it was built for
     tdgl::DevBuf<float> fusedR32;         // its values in fp32
+    tdgl::DevBuf<uint16_t> fusedR_off16;  // its columns as 16-bit offsets from fusedR_base[row], when they fit
+    tdgl::DevBuf<int32_t> fusedR_base;
     bool f32_ready = false;               // fp32 copies are current
     bool coarse32_ready = false;          // ... of the intermediate-level operators
     // two consecutive PCG iterations (odd, even) captured as a hipGraph: replayed while the
