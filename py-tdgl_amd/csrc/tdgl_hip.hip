@@ -39,7 +39,7 @@ static inline int grid_for(int64_t n, int block = BLOCK) { return (int)((n + blo
 // SELL construction from CSR (host)
 static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
                               const int32_t *indices, SellPattern &pat,
-                              std::vector<int64_t> *slot_of_nnz, bool want16 = false) {
+                              std::vector<int64_t> *slot_of_nnz, bool want16 = false, bool want_off16 = false) {
     pat.n_rows = n_rows;
     pat.n_pad = round_up(std::max<int64_t>(n_rows, 1), WAVE);
     pat.n_slices = (int32_t)(pat.n_pad / WAVE);
@@ -94,13 +94,43 @@ static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indp
             pat.use16 = true;
         }
     }
+    pat.use_off16 = false;
+    if (want_off16 && !getenv("TDGL_NO_INDEX16")) {
+        std::vector<uint16_t> o16(std::max<int64_t>(pat.n_slots, 1), 0);
+        std::vector<int32_t> sbase(std::max<int32_t>(pat.n_slices, 1), 0);
+        bool fits = true;
+        for (int sl = 0; sl < pat.n_slices && fits; ++sl) {
+            const int64_t rows_here = std::min<int64_t>(WAVE, n_rows - (int64_t)sl * WAVE);  // (padded lanes hold column 0)
+            int32_t lo = INT32_MAX, hi = 0;
+            for (int k = off[sl]; k < off[sl + 1]; ++k)
+                for (int lane = 0; lane < rows_here; ++lane) {
+                    lo = std::min(lo, cols[(int64_t)k * WAVE + lane]);
+                    hi = std::max(hi, cols[(int64_t)k * WAVE + lane]);
+                }
+            if (lo == INT32_MAX) lo = 0;
+            if ((int64_t)hi - lo > 65535) {
+                fits = false;
+                break;
+            }
+            sbase[sl] = lo;
+            for (int k = off[sl]; k < off[sl + 1]; ++k)
+                for (int lane = 0; lane < WAVE; ++lane)
+                    o16[(int64_t)k * WAVE + lane] = lane < rows_here ? (uint16_t)(cols[(int64_t)k * WAVE + lane] - lo) : 0;
+        }
+        if (fits) {
+            HIP_TRY(ctx, pat.offs16.upload(o16));
+            HIP_TRY(ctx, pat.slice_base.upload(sbase));
+            pat.use_off16 = true;
+        }
+    }
     return TDGL_OK;
 }
 
 static int build_sell_f64(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indptr,
-                          const int32_t *indices, const double *data, SellF64 &A, bool want16 = false) {
+                          const int32_t *indices, const double *data, SellF64 &A, bool want16 = false,
+                          bool want_off16 = false) {
     std::vector<int64_t> slot;
-    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr, indices, A.pat, &slot, want16));
+    TDGL_TRY(build_sell_pattern(ctx, n_rows, indptr, indices, A.pat, &slot, want16, want_off16));
     std::vector<double> vals(A.pat.n_slots, 0.0);
     for (int64_t k = 0; k < indptr[n_rows]; ++k) vals[slot[k]] = data[k];
     HIP_TRY(ctx, A.vals.upload(vals));

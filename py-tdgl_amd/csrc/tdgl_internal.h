@@ -74,6 +74,11 @@ struct SellPattern {
     // and only when every delta fits; kernels fall back to `cols` otherwise.
     DevBuf<int16_t> cols16;
     bool use16 = false;
+    // Rectangular operators (the level-0 prolongation): column - slice_base[slice] as 16 unsigned
+    // bits, when the columns of every 64-row slice span < 65536 (coarse numbering follows the fine one).
+    DevBuf<uint16_t> offs16;
+    DevBuf<int32_t> slice_base;
+    bool use_off16 = false;
 };
 
 struct SellF64 {
