@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--cheb-lo", type=float, default=0.1, help="Chebyshev smoothing interval [cheb_lo * rho, rho]")
     ap.add_argument("--precond-fp64", action="store_true",
                     help="keep the level-0 operators of the V-cycle in fp64 (default: fp32 storage inside the fp64 CG)")
+    ap.add_argument("--precond-fp32", action="store_true",
+                    help="fp32 storage only (default: fp32 and, for the three level-0 operator streams, binary16)")
     ap.add_argument("--no-fused-restriction", action="store_true",
                     help="restrict the level-0 residual with two kernels instead of the pre-multiplied operator")
     ap.add_argument("--no-collapse", action="store_true",
@@ -275,7 +277,7 @@ def main():
     popt = dict(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                 edge_currents_every_step=True, smoother=args.smoother, extrapolate=args.extrapolate,
                 nu_fine=args.nu_fine, fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
-                precond_fp32=not args.precond_fp64, collapse=not args.no_collapse, tail_cycles=args.tail_cycles,
+                precond_fp32=(False if args.precond_fp64 else 1 if args.precond_fp32 else True), collapse=not args.no_collapse, tail_cycles=args.tail_cycles,
                 guess_window=args.guess_window)
 
     def run_workload(name, want_cpu_state):
@@ -456,7 +458,8 @@ def main():
         config=dict(
             workload=f"{desc}, " + ("" if strip else f"uniform field b=B/Bc2={B_FIELD}, ") + f"adaptive dt (dt_init 1e-4, dt_max 0.1), "
                      f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
-                     + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32, all arithmetic and the CG in fp64")
+                     + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32"
+                        + ("" if args.precond_fp32 else " (level 0: binary16)") + ", all arithmetic and the CG in fp64")
                      + f"), J_s/J_n formed every step; steady state: {args.preroll} pre-roll + {args.warmup} warm-up steps "
                        f"untimed, then {args.steps} timed steps at {main_line['pcg']['mean_iterations']} PCG iterations per step",
             sites=r.n, edges=r.m, amg_levels=r.sizes, preroll=args.preroll,

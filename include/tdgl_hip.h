@@ -117,7 +117,11 @@ typedef struct {
                              residual recurrence, dot products, convergence test) uses fp64
                              data only, so the solution meets the same rtol.  Active with
                              nu_fine = 1 and a fused restriction (z is kept in fp64 in
-                             one-process-per-GPU mode, where its ghosts are exchanged).  */
+                             one-process-per-GPU mode, where its ghosts are exchanged).
+                             2 (default): in addition the three operator streams of level 0
+                             (fused restriction, prolongation, the matrix of the smoothing step)
+                             are stored in IEEE binary16 -- same PCG iteration count; falls back
+                             to 1 when an entry exceeds binary16's range.  0: everything fp64.  */
     int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..8 (0 = 6)   */
 } tdgl_poisson_options;
 
@@ -186,6 +190,10 @@ int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *ta
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);
+
+/* Storage of the V-cycle's operators in effect (after a solve): 0 fp64, 1 fp32, 2 fp32 and binary16 on
+ * level 0 (tdgl_poisson_options.precond_fp32). */
+int tdgl_get_precond_storage(tdgl_ctx *ctx, int32_t *mode);
 
 /* Quality of the last solve's initial guess: number of basis vectors it was projected on
  * (extrapolate = 3; 0 = none) and ||b - A x0|| / ||b||. */

@@ -18,6 +18,7 @@
 
 namespace tdgl {
 
+typedef _Float16 half_t;        // IEEE binary16 storage (level-0 V-cycle operators)
 constexpr int WAVE = 64;        // CDNA wavefront
 constexpr int BLOCK = 256;      // 4 waves per workgroup
 constexpr int XCDS = 8;         // MI355X accelerator complex dies (one L2 each)
@@ -107,6 +108,7 @@ struct AmgLevel {
     DevBuf<double> xa, xb, d, b, r;  // level vectors (level 0 borrows b from PCG)
     // fp32 copies of the level-0 V-cycle operators / iterates (mixed-precision preconditioner)
     DevBuf<float> A32, P32, dinv32, x32a, x32b;
+    DevBuf<half_t> A16, P16;         // the same operators in binary16 (popt.precond_fp32 == 2)
     // optional pre-multiplied operators of a coarse level (tdgl_poisson_set_fused_level)
     bool fused = false;
     Csr RA;                          // R A   [n_coarse x n]
@@ -236,6 +238,9 @@ struct tdgl_ctx {
     tdgl::Csr fusedR;                     // R0 (I - c A0 D0^-1): restriction of the pre-smoothed residual
     double fusedR_c = 0.0;                // the smoothing coefficient it was built for
     tdgl::DevBuf<float> fusedR32;         // its values in fp32
+    tdgl::DevBuf<tdgl::half_t> fusedR16;  // ... in binary16
+    bool level0_f16 = false;              // the level-0 V-cycle kernels read the binary16 copies
+    double level0_absmax = 0.0;           // largest |entry| of A0, P0 and the fused restriction (binary16 range check)
     tdgl::DevBuf<uint16_t> fusedR_off16;  // its columns as 16-bit offsets from fusedR_base[row], when they fit
     tdgl::DevBuf<int32_t> fusedR_base;
     bool f32_ready = false;               // fp32 copies are current
@@ -274,7 +279,7 @@ struct tdgl_ctx {
     // took it along
     bool xr_active = false, xr_carried = false;
     tdgl::XrArgs xr{};
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 1, 6};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6};
     // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
     // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
     // step's status block

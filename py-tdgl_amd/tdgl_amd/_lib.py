@@ -219,6 +219,7 @@ SIGNATURES = {
     "tdgl_profile_read_pcg": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
     "tdgl_profile_read": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
     "tdgl_profile_event_overhead": (C.c_int, [_CTX, C.c_int32, c_f64p]),
+    "tdgl_get_precond_storage": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
 }
 
 _lib = None

@@ -354,12 +354,14 @@ class TDGLContext:
                             extrapolate=3, nu_fine=1, fused_restriction=True, precond_fp32=True,
                             collapse=True, tail_cycles=2, guess_window=6):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
+        # storage of the V-cycle's operators: False / 0 fp64, 1 fp32, True / 2 fp32 + binary16 on level 0
+        precond_fp32 = 2 if precond_fp32 is True else int(precond_fp32)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
-                                int(extrapolate), int(nu_fine), int(bool(precond_fp32)), int(guess_window))
+                                int(extrapolate), int(nu_fine), precond_fp32, int(guess_window))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
-                                    fused_restriction=bool(fused_restriction), precond_fp32=bool(precond_fp32),
+                                    fused_restriction=bool(fused_restriction), precond_fp32=precond_fp32,
                                     edge_currents_every_step=bool(edge_currents_every_step),
                                     collapse=bool(collapse), tail_cycles=int(tail_cycles),
                                     guess_window=int(guess_window))
@@ -651,6 +653,12 @@ class TDGLContext:
         n, ms = C.c_int64(0), C.c_double(0)
         self._chk(self._lib.tdgl_profile_read_pcg(self._ctx, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def precond_storage(self) -> int:
+        """Storage of the V-cycle's operators in the last solve: 0 fp64, 1 fp32, 2 fp32 + binary16 on level 0."""
+        mode = C.c_int32(0)
+        self._chk(self._lib.tdgl_get_precond_storage(self._ctx, C.byref(mode)))
+        return mode.value
 
     def profile_event_overhead(self, reps: int = 50) -> float:
         """Mean reading (ms) of an event pair with nothing in between."""

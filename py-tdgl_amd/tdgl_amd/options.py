@@ -63,7 +63,9 @@ class SolverOptions:
     pcg_rtol: float = 1e-10
     pcg_max_iter: int = 500
     amg_smoothing_sweeps: int = 2  # Chebyshev degree of the AMG smoother
-    pcg_precond_fp32: bool = True  # store the V-cycle's operators in fp32 (arithmetic and CG stay fp64)
+    # storage of the V-cycle's operators (arithmetic and the CG stay fp64): True = fp32 and, on level 0,
+    # binary16; 1 = fp32 only; False = fp64
+    pcg_precond_fp32: bool = True
     edge_currents_every_step: bool = True
     device_id: int = 0
 

@@ -404,14 +404,18 @@ def test_trajectory_uniform_field_vortex_entry():
     assert (np.abs(sol.tdgl_data.psi) ** 2).min() < 0.05
 
 
-@pytest.mark.parametrize("precond_fp32", [True, False])
+@pytest.mark.parametrize("precond_fp32", [True, 1, False])
 def test_trajectory_fixed_dt(precond_fp32):
-    """(also: the V-cycle's operators stored in fp32 or fp64 -- same trajectory, the CG is fp64)"""
+    """(also: the V-cycle's operators stored in fp32 + binary16 on level 0, in fp32, or in fp64 -- same
+    trajectory, the CG is fp64)"""
     g = load_golden("traj_field_small_fixed_dt")
     mesh = reference_mesh(load_golden("mesh_small"))
     solver = _hip_solver(g, mesh, float(g["b"]), precond_fp32=precond_fp32)
-    assert solver.ctx.poisson_options["precond_fp32"] == precond_fp32
+    want_mode = 2 if precond_fp32 is True else int(precond_fp32)
+    assert solver.ctx.poisson_options["precond_fp32"] == want_mode
     sol = solver.solve()
+    # (a single-level hierarchy, <= 600 sites, has no reduced-precision operators at all)
+    assert solver.ctx.precond_storage() == (want_mode if len(solver.operators.hierarchy.sizes) > 1 else 0)
     _assert_hip_trajectory(g, sol, 2e-8)  # measured: 9e-10
     assert np.all(sol.dynamics.dt == float(g["opt_dt_init"]))
 
@@ -725,6 +729,7 @@ def test_strongly_irregular_mesh_matches_oracle():
     assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-8
     assert max_abs(got["normal_current"], want["normal_current"]) < 1e-8 * scale
     assert res["pcg_iters"].max() < 40
+    assert ctx.precond_storage() == 2  # binary16 level-0 operators, weights spread over four decades
 
 
 @pytest.mark.parametrize("lx, ly", [(1.0, 1.0), (2.0, 1.0), (3.0, 2.0), (6.0, 4.0), (9.0, 7.0), (30.0, 21.0)])
