@@ -165,6 +165,10 @@ int tdgl_poisson_set_fused_level(tdgl_ctx *ctx, int32_t level, const int32_t *ra
  *   - tdgl_poisson_set_collapsed_level(level, M): M = R (I - A S) [n_coarse x n] (CSR) of an
  *     intermediate level, S = the two-step pre-smoothing polynomial.  The next level's right-hand
  *     side M b and the pre-smoothing x = S b then share one launch.  m_indptr == NULL: off.
+ *   - tdgl_poisson_set_collapsed_up(level, W, V): the way up of that level as explicit operators,
+ *     e = W b + V e_next with W = T_x S + T_b [n x n] (pre- and post-smoothing as one polynomial in A)
+ *     and V = T_x P [n x n_coarse] (CSR both): together with M the level takes two launches and its
+ *     pre-smoothed iterate is never formed.  Needs M; w_indptr == NULL: off.
  *   - tdgl_poisson_set_collapsed_tail(t): everything from level t->level down.
  *       mode 0: e = G b, G = dense [n, n] (the cycle of that level formed explicitly, or the exact
  *               pseudo-inverse of its operator);
@@ -186,6 +190,9 @@ typedef struct {
 } tdgl_collapsed_tail;
 int tdgl_poisson_set_collapsed_level(tdgl_ctx *ctx, int32_t level, const int32_t *m_indptr, const int32_t *m_indices,
                                      const double *m_data);
+int tdgl_poisson_set_collapsed_up(tdgl_ctx *ctx, int32_t level, const int32_t *w_indptr, const int32_t *w_indices,
+                                  const double *w_data, const int32_t *v_indptr, const int32_t *v_indices,
+                                  const double *v_data);
 int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *tail);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */

@@ -117,6 +117,13 @@ struct AmgLevel {
     DevBuf<float> APp32;
     // collapsed coarse chain (tdgl_poisson_set_collapsed_level): M = R (I - A S) [n_coarse x n]
     Csr M;
+    // ... and the way up as explicit operators (tdgl_poisson_set_collapsed_up): e = Wup b - Vneg e_next,
+    // Wup = T_x S + T_b [n x n], Vneg = -T_x P [n x n_coarse]
+    Csr Wup, Vneg;
+    // compact forms for k_mid_up (when they fit): W columns = up_wbase[row] + up_woff, V columns 16-bit
+    DevBuf<int32_t> up_wbase;
+    DevBuf<uint16_t> up_woff, up_vidx;
+    DevBuf<half_t> up_w16, up_v16;   // binary16 values (popt.precond_fp32 >= 2)
 };
 
 // scalars of the PCG recurrence, resident on the device

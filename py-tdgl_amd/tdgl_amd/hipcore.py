@@ -332,6 +332,14 @@ class TDGLContext:
             else:
                 a = (i32(M.indptr), i32(M.indices), f64(M.data))
                 self._chk(lib.tdgl_poisson_set_collapsed_level(ctx, k, p_i32(a[0]), p_i32(a[1]), p_f64(a[2])))
+            up = None if plan is None else plan.get("up", {}).get(k)
+            if up is None:
+                self._chk(lib.tdgl_poisson_set_collapsed_up(ctx, k, None, None, None, None, None, None))
+            else:
+                W, V = up
+                a = (i32(W.indptr), i32(W.indices), f64(W.data), i32(V.indptr), i32(V.indices), f64(V.data))
+                self._chk(lib.tdgl_poisson_set_collapsed_up(ctx, k, p_i32(a[0]), p_i32(a[1]), p_f64(a[2]), p_i32(a[3]),
+                                                            p_i32(a[4]), p_f64(a[5])))
         if plan is None:
             self._chk(lib.tdgl_poisson_set_collapsed_tail(ctx, None))
             return
