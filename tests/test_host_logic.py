@@ -835,3 +835,70 @@ def test_solution_is_read_back_from_the_output_file(tmp_path, monkeypatch):
     assert mem.tdgl_data.step == 8 and mem.closest_solve_step(3.0) == 1
     with pytest.raises(IndexError):
         mem.load_tdgl_data(5)
+
+
+def test_public_api_keeps_the_reference_signatures():
+    """The drop-in surface: every parameter the reference's callables take is
+    taken here under the same name, in the same position, of the same kind, with the same default; the
+    build may add keyword arguments after them.  The reference's signatures are data recorded by
+    tests/golden/generate_api_signatures.py from the imported reference (v0.8.3)."""
+    import dataclasses
+    import inspect
+    import json
+
+    import tdgl_amd as tdgl
+    from tdgl_amd.solution import DynamicsData, TDGLData
+
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "api_signatures.json")))
+    ours = {
+        "solve": tdgl.solve, "TDGLSolver.__init__": tdgl.TDGLSolver.__init__, "TDGLSolver.update": tdgl.TDGLSolver.update,
+        "TDGLSolver.solve": tdgl.TDGLSolver.solve, "TDGLSolver.update_mu_boundary": tdgl.TDGLSolver.update_mu_boundary,
+        "MeshOperators.__init__": tdgl.MeshOperators.__init__,
+        "MeshOperators.set_link_exponents": tdgl.MeshOperators.set_link_exponents,
+        "MeshOperators.get_supercurrent": tdgl.MeshOperators.get_supercurrent,
+        "Parameter.__init__": tdgl.Parameter.__init__, "Parameter.__call__": tdgl.Parameter.__call__,
+        "CompositeParameter.__init__": tdgl.CompositeParameter.__init__,
+        "DynamicsData.mean_voltage": DynamicsData.mean_voltage, "DynamicsData.voltage": DynamicsData.voltage,
+        "DynamicsData.from_hdf5": DynamicsData.from_hdf5, "TDGLData.from_hdf5": TDGLData.from_hdf5,
+    }
+    assert set(ours) == set(ref["signatures"])
+    problems = []
+    for name, want in ref["signatures"].items():
+        have = [p for p in inspect.signature(ours[name]).parameters.values() if p.name != "self"]
+        have_by_name = {p.name: p for p in have}
+        for pos, (pname, kind, default) in enumerate(want):
+            p = have_by_name.get(pname)
+            if p is None:
+                problems.append(f"{name}: parameter {pname!r} missing")
+                continue
+            if p.kind.name != kind:
+                problems.append(f"{name}: {pname!r} is {p.kind.name}, reference {kind}")
+            if kind == "POSITIONAL_OR_KEYWORD" and have.index(p) != pos:
+                problems.append(f"{name}: {pname!r} at position {have.index(p)}, reference {pos}")
+            have_default = None if p.default is inspect.Parameter.empty else repr(p.default)
+            if default is not None and have_default is not None and float_or(default) != float_or(have_default):
+                problems.append(f"{name}: default of {pname!r} is {have_default}, reference {default}")
+            if default is not None and have_default is None:  # (a default where the reference has none is fine)
+                problems.append(f"{name}: {pname!r} is required, the reference defaults it to {default}")
+    fields = {f.name: f for f in dataclasses.fields(tdgl.SolverOptions)}
+    for fname, default in ref["SolverOptions.fields"]:
+        if fname not in fields:
+            problems.append(f"SolverOptions.{fname} missing")
+            continue
+        have = "MISSING" if fields[fname].default is dataclasses.MISSING else repr(fields[fname].default)
+        if fname == "sparse_solver":
+            assert "superlu" in have.lower()
+        elif float_or(have) != float_or(default):
+            problems.append(f"SolverOptions.{fname} default {have}, reference {default}")
+    assert list(tdgl.SolverResult._fields)[: len(ref["SolverResult.fields"])] == ref["SolverResult.fields"]
+    ops = tdgl.MeshOperators(synthetic_mesh(4))  # (no device work before build_operators)
+    for attr in ref["MeshOperators.attributes"]:
+        assert hasattr(ops, attr), attr
+    assert not problems, "\\n".join(problems)
+
+
+def float_or(text):
+    try:
+        return float(text)
+    except (TypeError, ValueError):
+        return text
