@@ -205,6 +205,10 @@ int tdgl_get_precond_storage(tdgl_ctx *ctx, int32_t *mode);
 /* Quality of the last solve's initial guess: number of basis vectors it was projected on
  * (extrapolate = 3; 0 = none) and ||b - A x0|| / ||b||. */
 int tdgl_get_guess_stats(tdgl_ctx *ctx, int32_t *vectors, double *initial_relres);
+/* The Gram matrix G_ij = x_i . b_j of the projection guess's window (k <= 8 vectors, row-major
+ * [k, k], oldest first; a diagonal entry still travelling with the next status block reads 0):
+ * a global quantity, identical on every rank of a decomposed run (tests). */
+int tdgl_get_guess_gram(tdgl_ctx *ctx, int32_t *k, double *G_rowmajor);
 /* Host-only: c = pinv(G) rhs for the k x k Gram matrix of the projection guess (eigen-decomposition,
  * directions below 1e-13 of the largest eigenvalue dropped).  No device work. */
 int tdgl_host_solve_gram(int32_t k, const double *G_rowmajor, const double *rhs, double *c);
@@ -370,6 +374,15 @@ int tdgl_get_loop_state(tdgl_ctx *ctx, int64_t *step, double *time, double *runn
 /* Overwrite the loop state (used by the host-side TDGLSolver.update() compatibility shim,
  * whose caller owns step/time like the reference's Runner does, runner.py:381-384). */
 int tdgl_set_loop_state(tdgl_ctx *ctx, int64_t step, double time, double runner_dt);
+
+/* The adaptive-dt controller's state (solver.py:316-320, 698-707): tentative_dt and the persistent
+ * list d_psi_sq_vals (the reference keeps it for the whole life of the solver; only the last
+ * `adaptive_window` entries are ever read).  get: the newest min(capacity, n) entries, oldest first,
+ * *n_history = entries held.  set: replaces both.  With tdgl_set_state / tdgl_set_loop_state this
+ * restarts a run from a recorded point (checkpoint/restart; bench.py's parity replay). */
+int tdgl_get_controller_state(tdgl_ctx *ctx, double *tentative_dt, double *history, int64_t capacity,
+                              int64_t *n_history);
+int tdgl_set_controller_state(tdgl_ctx *ctx, double tentative_dt, const double *history, int64_t n_history);
 
 /* Current fields in reference ordering; any pointer may be NULL.  supercurrent and
  * normal_current are [n_edges] (operators.py:385-394, solver.py:519). */

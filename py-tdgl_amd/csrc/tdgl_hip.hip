@@ -174,6 +174,7 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     hipStream_t s = ctx->stream;
     delete ctx;  // frees the DevBufs
     if (s) (void)hipStreamDestroy(s);
@@ -530,6 +531,7 @@ static void refresh_ceff(tdgl_ctx *ctx) {
 
 static int update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev);  // below
 static int apply_time_tables(tdgl_ctx *ctx);                                 // below
+static int profile_event(tdgl_ctx *ctx, hipEvent_t *ev);                     // below
 
 #include "comm.inc"
 #include "poisson.inc"
@@ -813,6 +815,7 @@ extern "C" int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_pr
     CTX_GUARD(ctx);
     if (n_probe < 0 || (n_probe > 0 && !sites)) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_probes: bad arguments");
     ctx->probes.clear();
+    ctx->probe_ring_count = 0;
     for (int k = 0; k < n_probe; ++k) {
         if (sites[k] < 0 || sites[k] >= ctx->n) TDGL_FAIL(ctx, TDGL_ERR_ARG, "probe site %d out of range", sites[k]);
         ctx->probes.push_back(ctx->iperm[sites[k]]);
@@ -823,8 +826,9 @@ extern "C" int tdgl_set_probes(tdgl_ctx *ctx, const int32_t *sites, int32_t n_pr
     }
     if (n_probe > 0) {
         HIP_TRY(ctx, ctx->d_probes.upload(ctx->probes));
-        HIP_TRY(ctx, ctx->d_probe_out.alloc(2 * n_probe));
-        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_probe_out), 2 * n_probe * sizeof(double)));
+        HIP_TRY(ctx, ctx->d_probe_out.alloc((size_t)PROBE_RING_STEPS * 2 * n_probe));
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_probe_out),
+                                   (size_t)PROBE_RING_STEPS * 2 * n_probe * sizeof(double)));
     }
     return TDGL_OK;
 }
@@ -1016,8 +1020,27 @@ extern "C" int tdgl_poisson_rhs(tdgl_ctx *ctx, const double *psi, double *rhs) {
 }
 
 // ---------------------------------------------------------------------------------------
+// an event for the in-run timers: from the pool when it has one (no creation in a timed region)
+static int profile_event(tdgl_ctx *ctx, hipEvent_t *ev) {
+    if (!ctx->prof_pool.empty()) {
+        *ev = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+        return TDGL_OK;
+    }
+    HIP_TRY(ctx, hipEventCreate(ev));
+    return TDGL_OK;
+}
+
 extern "C" int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on) {
     if (!ctx) return TDGL_ERR_ARG;
+    if (on) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        while (ctx->prof_pool.size() < 1024) {  // 448 timed steps + the 64 sampled A p launches per read-out
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->prof_pool.push_back(e);
+        }
+    }
     ctx->profile = on != 0;
     ctx->prof_launches = 0;
     ctx->prof_ms = 0.0;
@@ -1035,8 +1058,8 @@ static int profile_drain(tdgl_ctx *ctx) {
         HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
         ctx->prof_ms += ms;
         ctx->prof_launches += 1;
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        ctx->prof_pool.push_back(pr.first);
+        ctx->prof_pool.push_back(pr.second);
     }
     ctx->prof_pending.clear();
     for (auto &pr : ctx->prof2_pending) {
@@ -1045,8 +1068,8 @@ static int profile_drain(tdgl_ctx *ctx) {
         HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
         ctx->prof2_ms += ms;
         ctx->prof2_launches += 1;
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        ctx->prof_pool.push_back(pr.first);
+        ctx->prof_pool.push_back(pr.second);
     }
     ctx->prof2_pending.clear();
     return TDGL_OK;

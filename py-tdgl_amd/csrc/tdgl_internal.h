@@ -23,6 +23,7 @@ constexpr int WAVE = 64;        // CDNA wavefront
 constexpr int BLOCK = 256;      // 4 waves per workgroup
 constexpr int XCDS = 8;         // MI355X accelerator complex dies (one L2 each)
 constexpr int REDUCE_BLOCK = 1024;
+constexpr int PROBE_RING_STEPS = 1024;  // steps of probe read-outs kept on the device between flushes
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -294,6 +295,7 @@ struct tdgl_ctx {
     int g_slot[tdgl::GUESS_MAX] = {0};
     int g_count = 0;
     bool g_diag_pending = false;
+    bool mu_first_saved = false;          // mu_prev holds mu^n of a solve that started without a basis
     double g_G[tdgl::GUESS_MAX][tdgl::GUESS_MAX] = {{0}};
     double g_rhs[tdgl::GUESS_MAX] = {0};
     tdgl::DevBuf<double> part_gdot;       // (GUESS_MAX + 3) x NB partials: [x_j . b | b . b | x_new . b_new | sum b]
@@ -314,8 +316,9 @@ struct tdgl_ctx {
     bool status_copy = false;
     std::vector<int32_t> probes;           // internal site ids
     tdgl::DevBuf<int32_t> d_probes;
-    tdgl::DevBuf<double> d_probe_out;      // [2 * n_probe]
-    double *h_probe_out = nullptr;         // pinned
+    tdgl::DevBuf<double> d_probe_out;      // ring buffer [PROBE_RING_STEPS][2 * n_probe]: mu | theta per step
+    double *h_probe_out = nullptr;         // pinned, same shape
+    int probe_ring_count = 0;              // steps written since the last flush (run.inc: probe_ring_flush)
 
     // ---- controller / loop state (host; mirrors solver.py:316-320, runner.py:260-263) --
     tdgl_controller ctl{1e-6, 1e-1, 1, 10, 10, 0.25};
@@ -349,6 +352,8 @@ struct tdgl_ctx {
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+    std::vector<hipEvent_t> prof_pool;     // created by tdgl_profile_enable, recycled by profile_drain: no
+                                           // hipEventCreate inside a timed region
     // the same for the kernel that dominates the run time (the CG's fused A p), sampled: only the
     // first prof2_budget launches after tdgl_profile_enable are bracketed by events
     int64_t prof2_launches = 0, prof2_budget = 0, prof2_seen = 0;

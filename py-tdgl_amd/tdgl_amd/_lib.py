@@ -150,6 +150,7 @@ SIGNATURES = {
     "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
     "tdgl_get_poisson_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     "tdgl_get_guess_stats": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
+    "tdgl_get_guess_gram": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
     "tdgl_host_solve_gram": (C.c_int, [C.c_int32, c_f64p, c_f64p, c_f64p]),
     "tdgl_poisson_set_fused_level": (
         C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p]
@@ -201,6 +202,8 @@ SIGNATURES = {
         [_CTX, C.POINTER(C.c_int64), c_f64p, c_f64p, c_f64p],
     ),
     "tdgl_set_loop_state": (C.c_int, [_CTX, C.c_int64, C.c_double, C.c_double]),
+    "tdgl_get_controller_state": (C.c_int, [_CTX, c_f64p, c_f64p, C.c_int64, C.POINTER(C.c_int64)]),
+    "tdgl_set_controller_state": (C.c_int, [_CTX, C.c_double, c_f64p, C.c_int64]),
     "tdgl_get_state": (C.c_int, [_CTX, c_f64p, c_f64p, c_f64p, c_f64p]),
     "tdgl_apply_psi_laplacian": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_supercurrent": (C.c_int, [_CTX, c_f64p, c_f64p]),

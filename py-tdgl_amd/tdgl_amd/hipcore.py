@@ -363,7 +363,9 @@ class TDGLContext:
                             collapse=True, tail_cycles=2, guess_window=6):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         # storage of the V-cycle's operators: False / 0 fp64, 1 fp32, True / 2 fp32 + binary16 on level 0
-        precond_fp32 = 2 if precond_fp32 is True else int(precond_fp32)
+        from .options import precond_storage_mode
+
+        precond_fp32 = precond_storage_mode(precond_fp32)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
                                 int(extrapolate), int(nu_fine), precond_fp32, int(guess_window))
@@ -545,6 +547,19 @@ class TDGLContext:
     def set_loop_state(self, step, time, runner_dt):
         self._chk(self._lib.tdgl_set_loop_state(self._ctx, int(step), float(time), float(runner_dt)))
 
+    def controller_state(self, capacity=4096):
+        """``dict(tentative_dt, history)`` of the adaptive-dt controller (solver.py:316-320): the
+        newest ``capacity`` entries of ``d_psi_sq_vals``, oldest first."""
+        tdt, n = C.c_double(0), C.c_int64(0)
+        hist = np.zeros(int(capacity))
+        self._chk(self._lib.tdgl_get_controller_state(self._ctx, C.byref(tdt), p_f64(hist), int(capacity), C.byref(n)))
+        return dict(tentative_dt=tdt.value, history=hist[:min(n.value, int(capacity))].copy())
+
+    def set_controller_state(self, tentative_dt, history=()):
+        hist = f64(history)
+        self._chk(self._lib.tdgl_set_controller_state(self._ctx, float(tentative_dt), p_f64(hist) if len(hist) else None,
+                                                      len(hist)))
+
     def get_state(self, psi=True, mu=True, supercurrent=True, normal_current=True):
         out = {}
         a_psi = np.empty(self.n, dtype=np.complex128) if psi else None
@@ -634,6 +649,13 @@ class TDGLContext:
         k, r = C.c_int32(0), C.c_double(0)
         self._chk(self._lib.tdgl_get_guess_stats(self._ctx, C.byref(k), C.byref(r)))
         return dict(vectors=k.value, initial_relres=r.value)
+
+    def guess_gram(self):
+        """Gram matrix ``G_ij = x_i . b_j`` of the projection guess's window (``[k, k]``, oldest first)."""
+        k = C.c_int32(0)
+        G = np.zeros(64)
+        self._chk(self._lib.tdgl_get_guess_gram(self._ctx, C.byref(k), p_f64(G)))
+        return G[:k.value * k.value].reshape(k.value, k.value).copy()
 
     def poisson_solve(self, rhs, mu0=None):
         rhs = f64(rhs)

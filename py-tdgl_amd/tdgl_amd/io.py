@@ -106,6 +106,7 @@ class DataHandler:
         self.output_path = self.tmp_path = None
         self.time_step_group = self.mesh_group = None
         self.save_number = 0
+        self._swmr = False
 
     def _create_output_file(self, output):
         import os
@@ -192,6 +193,12 @@ class DataHandler:
             running_grp = group.create_group("running_state")
             for key, value in running_state.items():
                 running_grp[key] = np.squeeze(np.asarray(value))
+        # runner.py:402-403: once the first step is saved the latest-step file goes into single-writer /
+        # multiple-reader mode, which is what lets the reference's live monitor open it (swmr=True) while
+        # the run is in progress.  (File objects without the attribute skip it.)
+        if not self._swmr and hasattr(self.tmp_file, "swmr_mode"):
+            self.tmp_file.swmr_mode = True
+        self._swmr = True
 
 
 def write_solution_group(file, solution) -> None:

@@ -89,10 +89,13 @@ class MeshOperators:
             rtol=o["pcg_rtol"], max_iter=o["pcg_max_iter"], nu=o["nu"],
             edge_currents_every_step=o["edge_currents_every_step"],
         )
-        if o["precond_fp32"] is not True:  # (True = the default: fp32 + binary16 on level 0)
+        from .options import precond_storage_mode
+
+        mode = precond_storage_mode(o["precond_fp32"])
+        if mode != self.ctx.poisson_options["precond_fp32"]:  # (the default is 2: fp32 + binary16 on level 0)
             po = dict(self.ctx.poisson_options)
             po["smoother"] = "jacobi" if po["smoother"] == 0 else "chebyshev"
-            po["precond_fp32"] = int(o["precond_fp32"])
+            po["precond_fp32"] = mode
             self.ctx.set_poisson_options(**po)
         n, m = self.ctx.n, self.ctx.m
         ctx = self.ctx

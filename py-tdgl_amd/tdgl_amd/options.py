@@ -33,6 +33,20 @@ class SparseSolver(Enum):
     AMG_PCG = "amg_pcg"
 
 
+def precond_storage_mode(value) -> int:
+    """Storage of the V-cycle's operators as the C ABI's code: 0 fp64, 1 fp32, 2 fp32 + binary16 on
+    level 0.  Booleans of any flavour (``True``, ``numpy.bool_`` -- what an HDF5 attribute comes back
+    as) mean 2 / 0; the integers 0, 1, 2 mean themselves.  Compared by value, never by identity."""
+    import numpy as np
+
+    if isinstance(value, (bool, np.bool_)):
+        return 2 if bool(value) else 0
+    mode = int(value)
+    if mode not in (0, 1, 2):
+        raise SolverOptionsError(f"pcg_precond_fp32 must be a bool or 0, 1, 2 (got {value!r}).")
+    return mode
+
+
 @dataclass
 class SolverOptions:
     solve_time: float  # simulated time after thermalisation, in units of tau_0
@@ -65,7 +79,7 @@ class SolverOptions:
     amg_smoothing_sweeps: int = 2  # Chebyshev degree of the AMG smoother
     # storage of the V-cycle's operators (arithmetic and the CG stay fp64): True = fp32 and, on level 0,
     # binary16; 1 = fp32 only; False = fp64
-    pcg_precond_fp32: bool = True
+    pcg_precond_fp32: Union[bool, int] = True
     edge_currents_every_step: bool = True
     device_id: int = 0
 
@@ -103,6 +117,7 @@ class SolverOptions:
             fail(f"pcg_rtol must be > 0 (got {self.pcg_rtol}).")
         if self.pcg_max_iter < 1 or self.amg_smoothing_sweeps < 1:
             fail("pcg_max_iter and amg_smoothing_sweeps must be >= 1.")
+        precond_storage_mode(self.pcg_precond_fp32)
         if self.adaptive_window < 0:
             fail(f"adaptive_window must be >= 0 (got {self.adaptive_window}).")
         if self.save_every < 1:

@@ -308,7 +308,9 @@ class Solution:
                     return cloudpickle.loads(np.void(np.array(grp[f"{name}.pickle"])).tobytes())
                 raise IOError(f"Unable to load {name}.")
 
-            options = SolverOptions(**dict(grp["options"].attrs))
+            # (HDF5 attributes come back as NumPy scalars: numpy.bool_, numpy.int64, ...)
+            options = SolverOptions(**{k: (v.item() if isinstance(v, np.generic) else v)
+                                       for k, v in dict(grp["options"].attrs).items()})
             options.validate()
             solution = Solution(
                 device=Device.from_hdf5(grp["device"]), options=options,

@@ -480,14 +480,19 @@ class TDGLSolver:
 
         running = RunningState(sizes, opts.save_every)
         if opts.output_file is not None:
-            handler = DataHandler(opts.output_file, file_factory=getattr(self, "_h5_file_factory", None)).__enter__()
-            handler.save_mesh(self.device.mesh)
-            fixed = {}
-            if not self.dynamic_vector_potential:
-                fixed["applied_vector_potential"] = self.current_A_applied
-            if not self.dynamic_epsilon:
-                fixed["epsilon"] = self.epsilon
-            handler.save_fixed_values(fixed)
+            handler = DataHandler(opts.output_file, file_factory=getattr(self, "_h5_file_factory", None))
+            try:
+                handler.__enter__()
+                handler.save_mesh(self.device.mesh)
+                fixed = {}
+                if not self.dynamic_vector_potential:
+                    fixed["applied_vector_potential"] = self.current_A_applied
+                if not self.dynamic_epsilon:
+                    fixed["epsilon"] = self.epsilon
+                handler.save_fixed_values(fixed)
+            except BaseException:
+                handler.close()  # no open files / stray .tmp left behind
+                raise
 
         def save_step(final=False):
             ls = ctx.loop_state()

@@ -97,6 +97,19 @@ def _strip_device():
     return dev
 
 
+def test_precond_storage_option_is_compared_by_value():
+    """`SolverOptions.pcg_precond_fp32` carries three states; booleans of any flavour (an HDF5 attribute
+    comes back as numpy.bool_) must select the same storage as the Python singletons."""
+    from tdgl_amd import SolverOptions
+    from tdgl_amd.options import SolverOptionsError, precond_storage_mode
+
+    assert [precond_storage_mode(v) for v in (True, np.bool_(True), False, np.bool_(False), 0, 1, 2, np.int64(1))] == \
+        [2, 2, 0, 0, 0, 1, 2, 1]
+    with pytest.raises(SolverOptionsError):
+        SolverOptions(solve_time=1.0, pcg_precond_fp32=3).validate()
+    SolverOptions(solve_time=1.0, pcg_precond_fp32=np.bool_(True)).validate()
+
+
 def test_device_mesh_terminals_and_probes():
     dev = _strip_device()
     mesh = dev.mesh
@@ -578,6 +591,7 @@ def test_data_handler_streams_the_reference_layout(tmp_path, monkeypatch):
         h.save_time_step(dict(step=n_steps, time=t, dt=float(dts[-1])), fields_at["end"], running.export())
         tmp, out = h.tmp_file, h.output_file
         assert tmp.kw == {"libver": "latest"}
+        assert tmp.swmr_mode is True and out.swmr_mode is False  # runner.py:402-403: the monitor's file only
         # the latest-step file holds ONE group, overwritten in place and flushed per dataset
         assert set(tmp["data"]) == {"-1"} and tmp["data/-1/step"][0] == n_steps
         assert np.array_equal(tmp["data/-1/psi"].value, fields_at["end"]["psi"]) and tmp["data/-1/psi"].flushes == 4
