@@ -50,7 +50,10 @@ WORKLOADS = {
     "4M": (1860.0, "square film 1860 xi, 3,998,502 sites"),
     # BASELINE config 4: strip with two current terminals (short edges), I = 0.2 * Ly, zero field
     "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly"),
+    # the same strip driven above the depairing current density (2 / (3 sqrt 3) = 0.385 in these units): phase slips
+    "strip500k_ps": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.45 Ly (above the critical current: phase slips)"),
 }
+STRIP_CURRENT = {"strip500k": 0.2, "strip500k_ps": 0.45}
 B_FIELD = 0.1  # B / Bc2
 
 
@@ -96,10 +99,15 @@ def traffic_of(table, prefix):
     return None
 
 
-def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, terms=(), currents=None):
-    """Time the oracle (NumPy/SciPy port of the reference step: SuperLU + sparse matvecs) on
-    this host, starting from the GPU run's post-warm-up state.  Setup (operator build, LU
-    factorisation) is excluded, like the GPU path's setup."""
+def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, terms=(), currents=None, keep_at=0,
+                 probes=None):
+    """Time the oracle (NumPy/SciPy port of the reference step: SuperLU + sparse matvecs) on this host,
+    starting from the GPU run's post-warm-up state -- fields, loop state and the adaptive-dt
+    controller's history, so that it takes the very steps the timed GPU window took.  Setup (operator
+    build, LU factorisation) is excluded, like the GPU path's setup.
+
+    Returns ``(baseline, run)``: the ``cpu_baseline`` object of the JSON line, and the oracle's dt
+    sequence plus its fields after ``keep_at`` steps (the checker's side of ``parity_vs_oracle``)."""
     from oracle import OracleSolver
 
     o = SimpleNamespace(skip_time=0.0, terminal_psi=0.0, **opt_kw)
@@ -108,28 +116,63 @@ def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, term
                           current_func=None if currents is None else (lambda t: currents))
     setup_s = time.perf_counter() - t0
     solver.tentative_dt = state["tentative_dt"]
+    solver.d_psi_sq_vals = [float(v) for v in state["history"]]  # solver.py:318: the list persists
     psi, mu = state["psi"].copy(), state["mu"].copy()
-    t, dt = state["time"], state["dt"]
-    step0 = 10**6  # past the adaptive window, like the GPU run after warm-up
-    # one untimed step (first-touch effects), then time
-    dt, psi, mu, _, _ = solver.update({"step": step0, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
-    n_done, t_start = 0, time.perf_counter()
+    t, dt, step0 = state["time"], state["dt"], int(state["step"])
+    dts, kept = [], None
+    n_done, n_timed, t_start = 0, 0, None
     while n_done < max_steps:
-        dt, psi, mu, _, _ = solver.update({"step": step0 + 1 + n_done, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
-        t += dt
+        new_dt, psi, mu, js, jn = solver.update({"step": step0 + n_done, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
+        dts.append(float(new_dt))
         n_done += 1
-        if time.perf_counter() - t_start > target_seconds:
-            break
+        if n_done == keep_at:
+            kept = dict(psi=psi.copy(), mu=mu.copy(), supercurrent=js.copy(), normal_current=jn.copy())
+        dt = new_dt  # runner.py:431-433
+        t += dt
+        if t_start is None:
+            t_start = time.perf_counter()  # the first step is untimed (first-touch effects)
+        else:
+            n_timed += 1
+            if time.perf_counter() - t_start > target_seconds and n_done >= keep_at:
+                break
     elapsed = time.perf_counter() - t_start
-    return dict(
-        value=n_done / elapsed,
+    base = dict(
+        value=n_timed / elapsed,
         unit="steps/s",
         cores=1,
         kind="port",
-        sample=f"{n_done} steps of the same workload from the GPU run's post-warm-up state; "
-               f"oracle = NumPy/SciPy restatement (scipy SuperLU solve + sparse matvecs, single thread); "
-               f"setup excluded ({setup_s:.0f} s, mostly LU factorisation); host has {os.cpu_count()} logical cores",
+        sample=f"{n_timed} steps (after one untimed step) of the same workload from the GPU run's post-warm-up state, "
+               f"same dt controller history; oracle = NumPy/SciPy restatement (scipy SuperLU solve + sparse matvecs, "
+               f"single thread); setup excluded ({setup_s:.0f} s, mostly LU factorisation); host has {os.cpu_count()} logical cores",
     )
+    return base, dict(dt=np.array(dts), kept=kept, keep_at=keep_at)
+
+
+PARITY_TOL = 1e-8
+PARITY_STEPS = 20
+
+
+def parity_block(hip_dt, hip_state, oracle_run, source):
+    """``parity_vs_oracle``: the HIP path's K steps against the oracle's K steps from the same state.
+    Deviations are max-abs, divided by max(1, max|reference|) of the field; mu is compared with its
+    mean removed (the reference's additive constant is SuperLU round-off)."""
+    K, ref = oracle_run["keep_at"], oracle_run["kept"]
+
+    def dev(a, b):
+        return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+    out = dict(
+        steps=K, source=source, tolerance=PARITY_TOL,
+        dt=float(np.max(np.abs(hip_dt[:K] - oracle_run["dt"][:K])) / np.max(oracle_run["dt"][:K])),
+        abs_sq_psi=dev(np.abs(hip_state["psi"]) ** 2, np.abs(ref["psi"]) ** 2),
+        mu_zero_mean=dev(hip_state["mu"] - hip_state["mu"].mean(), ref["mu"] - ref["mu"].mean()),
+        J_s=dev(hip_state["supercurrent"], ref["supercurrent"]),
+        J_n=dev(hip_state["normal_current"], ref["normal_current"]),
+        scales=dict(mu=float(np.max(np.abs(ref["mu"] - ref["mu"].mean()))), J_s=float(np.max(np.abs(ref["supercurrent"]))),
+                    J_n=float(np.max(np.abs(ref["normal_current"])))),
+    )
+    out["ok"] = bool(all(out[k] <= PARITY_TOL for k in ("dt", "abs_sq_psi", "mu_zero_mean", "J_s", "J_n")))
+    return out
 
 
 def build_workload(name):
@@ -157,8 +200,14 @@ def build_workload(name):
                         site_indices=np.intersect1d(np.flatnonzero(np.isclose(mesh.sites[:, 0], x0)), mesh.boundary_indices))
 
         terms = [terminal("source", -side[0] / 2), terminal("drain", side[0] / 2)]
-        currents = {"source": 0.2 * side[1], "drain": -0.2 * side[1]}
-    return SimpleNamespace(name=name, desc=desc, strip=strip, mesh=mesh, A=A, terms=terms, currents=currents, n=n, m=m)
+        cur = STRIP_CURRENT[name] * side[1]
+        currents = {"source": cur, "drain": -cur}
+        # probe points at (+-Lx/4, 0)
+        probes = [mesh.closest_site((-side[0] / 4, 0.0)), mesh.closest_site((side[0] / 4, 0.0))]
+    else:
+        probes = None
+    return SimpleNamespace(name=name, desc=desc, strip=strip, mesh=mesh, A=A, terms=terms, currents=currents, n=n, m=m,
+                           probes=probes, mesh_s=time.perf_counter() - t0)
 
 
 OPT_KW = dict(solve_time=1e12, dt_init=1e-4, dt_max=0.1, adaptive=True, adaptive_window=10,
@@ -231,6 +280,14 @@ def main():
     ap.add_argument("--tail-cycles", type=int, default=2,
                     help="V-cycles folded into the explicit operators of the tail level (1 = the plain cycle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip `parity_vs_oracle` (it needs the CPU baseline leg: the oracle's steps are the reference side)")
+    ap.add_argument("--no-probes", action="store_true", help="strip workloads: run without the two probe points")
+    ap.add_argument("--vortex-window", choices=["auto", "on", "off"], default="auto",
+                    help="after the headline window, run on until the order parameter has collapsed somewhere "
+                         "(min |psi|^2 < 0.05; vortices / phase slips) and time a second window there; auto = single GPU")
+    ap.add_argument("--vortex-max-steps", type=int, default=5000, help="steps the search for that state may take")
+    ap.add_argument("--vortex-settle", type=int, default=500, help="steps between reaching that state and the window")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the domain-decomposition driver (RCCL communicator) even on one GPU")
@@ -289,7 +346,8 @@ def main():
             raise SystemExit("the strip workload is single-GPU in bench.py")
         drun = None
         if not use_dd:
-            solver = TDGLSolver.from_dimensionless(wl.mesh, opts, wl.A, 1.0, terminal_info=wl.terms, current_func=wl.currents)
+            solver = TDGLSolver.from_dimensionless(wl.mesh, opts, wl.A, 1.0, terminal_info=wl.terms, current_func=wl.currents,
+                                                   probe_points=None if args.no_probes else wl.probes)
             solver.update_mu_boundary(0.0)
             ctx = solver.ctx
             n_loc, m_loc, n, m = wl.n, wl.m, wl.n, wl.m
@@ -308,7 +366,11 @@ def main():
             log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
         ctx.set_poisson_options(**popt)
         h = ctx.hierarchy
-        log(f"rank {rank}: {name} set-up {time.perf_counter() - t0:.1f} s; AMG levels {h.sizes}, "
+        total_s = time.perf_counter() - t0
+        st = dict(getattr(ctx, "setup_times", {}))
+        setup = dict(mesh=round(wl.mesh_s, 2) if wl is not None else None, reorder=round(st.get("reorder", 0.0), 2),
+                     amg_host=round(st.get("amg_host", 0.0), 2), upload=round(st.get("upload", 0.0), 2), total=round(total_s, 2))
+        log(f"rank {rank}: {name} set-up {total_s:.1f} s {setup}; AMG levels {h.sizes}, "
             f"operator complexity {h.operator_complexity:.2f}")
         ctx.begin_stage()
 
@@ -326,11 +388,13 @@ def main():
         start_state = None
         if want_cpu_state:
             st = ctx.get_state(supercurrent=False, normal_current=False)
-            ls = ctx.loop_state()
-            start_state = dict(psi=st["psi"], mu=st["mu"], time=ls["time"], dt=ls["dt"], tentative_dt=ls["tentative_dt"])
+            ls, cs = ctx.loop_state(), ctx.controller_state()
+            start_state = dict(psi=st["psi"], mu=st["mu"], step=ls["step"], time=ls["time"], dt=ls["dt"],
+                               tentative_dt=cs["tentative_dt"], history=cs["history"])
         # ---- timed region: exactly K steps ---------------------------------------------------
         ctx.profile_enable(True)
         ctx.comm_stats(reset=True)
+        ctx.step_stats(reset=True)
         barrier()
         t_begin = time.perf_counter()
         res = ctx.run(args.steps)
@@ -341,8 +405,11 @@ def main():
         launches, k1_ms = ctx.profile_read()
         axp_launches, axp_ms = ctx.profile_read_pcg() if not use_dd else (0, 0.0)
         ctx.profile_enable(False)
+        work = ctx.step_stats()
         ev_over = ctx.profile_event_overhead(50)  # (after the timed region)
         comm = ctx.comm_stats()
+        # parity_vs_oracle, direct form: the fields the timed steps themselves ended on
+        end_state = ctx.get_state() if (want_cpu_state and not args.no_parity and args.steps <= PARITY_STEPS) else None
         if dist is not None:
             import torch
 
@@ -352,6 +419,7 @@ def main():
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
+            end_state=end_state, work=work, setup=setup,
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats()), overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
@@ -360,6 +428,55 @@ def main():
         return out
 
     main_run = run_workload(args.workload, want_cpu_state=(rank == 0 and not use_dd and not args.no_cpu_baseline))
+    def vortex_window(r):
+        """The regime the headline window does not see: run on until the order parameter has collapsed
+        somewhere (min |psi|^2 < 0.05 outside the terminals: vortex cores / phase slips), let the
+        dynamics settle for --vortex-settle steps, then time --steps steps there."""
+        ctx, wl = r.ctx, r.wl
+        free = np.ones(r.n, dtype=bool)
+        for t in wl.terms:
+            free[np.asarray(t["site_indices"])] = False
+        total, found, search, dts, its = 0, None, [], [], []
+        while total < args.vortex_max_steps:
+            res = ctx.run(250)
+            total += len(res["dt"])
+            dts.append(res["dt"])
+            its.append(res["pcg_iters"])
+            a2 = np.abs(ctx.get_state(mu=False, supercurrent=False, normal_current=False)["psi"][free]) ** 2
+            search.append(dict(steps_after_headline=total, min_abs_sq_psi=float(a2.min()), sites_below_0p1=int((a2 < 0.1).sum()),
+                               dt_last=float(res["dt"][-1]), dt_min=float(res["dt"].min()), pcg_mean=float(res["pcg_iters"].mean())))
+            if found is None and a2.min() < 0.05:
+                found = total
+            if found is not None and total >= found + args.vortex_settle:
+                break
+        ctx.step_stats(reset=True)
+        ctx.synchronize()
+        t_begin = time.perf_counter()
+        res = ctx.run(args.steps)
+        ctx.synchronize()
+        elapsed = time.perf_counter() - t_begin
+        work, ls = ctx.step_stats(), ctx.loop_state()
+        dts.append(res["dt"])
+        its.append(res["pcg_iters"])
+        r.trace["dt"] += np.concatenate(dts).tolist()
+        r.trace["pcg_iters"] += np.concatenate(its).tolist()
+        r.trace["vortex_search"] = search
+        return dict(
+            value=round(args.steps / elapsed, 3), unit="steps/s", ms_per_step=round(1e3 * elapsed / args.steps, 4), steps=args.steps,
+            state_reached=found is not None, steps_before_window=args.preroll + args.warmup + args.steps + total,
+            simulated_time=round(ls["time"], 3), min_abs_sq_psi=search[-1]["min_abs_sq_psi"],
+            sites_below_0p1=search[-1]["sites_below_0p1"],
+            pcg=dict(mean_iterations=round(float(res["pcg_iters"].mean()), 2), max_iterations=int(res["pcg_iters"].max())),
+            retries=int(work["psi_retries"]), host_syncs_per_step=round(work["host_syncs"] / max(work["steps"], 1), 2),
+            dt=dict(mean=float(res["dt"].mean()), min=float(res["dt"].min()), max=float(res["dt"].max())),
+            guess=ctx.guess_stats(),
+        )
+
+    vortex = None
+    want_vortex = args.vortex_window == "on" or (args.vortex_window == "auto" and not use_dd)
+    if want_vortex and rank == 0 and not use_dd:
+        vortex = vortex_window(main_run)
+        log(f"vortex window: {vortex}")
     if args.trace_iterations and rank == 0:
         with open(args.trace_iterations, "w") as f:
             json.dump(dict(workload=args.workload, preroll=args.preroll, warmup=args.warmup, steps=args.steps,
@@ -470,7 +587,14 @@ def main():
         roofline_pcg=roofline_pcg,
         pcg=main_line["pcg"],
         step_aggregate=main_line["step_aggregate"],
+        # what a step costs the host: synchronisations and repeated psi updates in the timed window
+        host=dict(syncs_per_step=round(r.work["host_syncs"] / max(r.work["steps"], 1), 2), psi_retries=int(r.work["psi_retries"]),
+                  probes=0 if (r.wl is None or r.wl.probes is None or args.no_probes) else len(r.wl.probes)),
+        # seconds before the first step (not in `value`): meshing, RCM, AMG set-up on the host, uploads
+        setup_s=r.setup,
     )
+    if vortex is not None:
+        out["vortex_window"] = vortex
     if rank == 0 and "comm_per_step" in main_line:
         out["comm_per_step"] = main_line["comm_per_step"]
     # BASELINE config 5 next to the headline workload (decomposed runs).  The headline measurement is
@@ -510,17 +634,42 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    parity_failed = False
     if r.start_state is not None:
         log("timing the CPU oracle (LU factorisation first; this takes a while at 1M sites)")
         wl = r.wl
-        out["cpu_baseline"] = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
-                                           terms=wl.terms, currents=wl.currents)
-        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 4)
+        want_parity = not args.no_parity
+        K = min(args.steps, PARITY_STEPS) if want_parity else 0
+        base, oracle_run = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
+                                        terms=wl.terms, currents=wl.currents, keep_at=K)
+        out["cpu_baseline"] = base
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / base["value"], 1)
+        base["value"] = round(base["value"], 4)
+        if want_parity:
+            if r.end_state is not None:  # the timed window itself was K steps long
+                hip_dt, hip_state, source = r.res["dt"], r.end_state, "the timed steps themselves"
+            else:
+                # the timed window is longer than the oracle can follow: its first K steps are taken again
+                # from the recorded start state (fields, loop state, dt controller history)
+                st0 = r.start_state
+                r.ctx.set_state(st0["psi"], st0["mu"])
+                r.ctx.set_loop_state(st0["step"], st0["time"], st0["dt"])
+                r.ctx.set_controller_state(st0["tentative_dt"], st0["history"])
+                replay = r.ctx.run(K)
+                hip_dt, hip_state = replay["dt"], r.ctx.get_state()
+                redo = float(np.max(np.abs(replay["dt"] - r.res["dt"][:K])) / np.max(replay["dt"]))
+                source = (f"first {K} of the {args.steps} timed steps, taken again from the recorded start state "
+                          f"(dt sequence of the replay vs the timed run: {redo:.1e} relative)")
+            out["parity_vs_oracle"] = parity_block(hip_dt, hip_state, oracle_run, source)
+            parity_failed = not out["parity_vs_oracle"]["ok"]
+            log(f"parity vs oracle: {out['parity_vs_oracle']}")
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        log(f"PARITY FAILURE: a deviation from the oracle exceeds {PARITY_TOL:g}")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -326,6 +326,9 @@ struct tdgl_ctx {
     std::vector<double> d_psi_sq_vals;
     double runner_dt = 1e-6, time = 0.0;
     int64_t stage_step = 0;
+    // counters since the last reset (tdgl_get_step_stats): steps accepted, failed psi updates that were
+    // repeated with a smaller dt, PCG iterations, host synchronisations inside tdgl_run
+    int64_t stat_steps = 0, stat_psi_retries = 0, stat_pcg_iters = 0, stat_host_syncs = 0;
 
     // ---- screening (screening.inc) -------------------------------------------------------
     bool scr_enabled = false;

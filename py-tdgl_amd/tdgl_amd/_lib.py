@@ -197,6 +197,7 @@ SIGNATURES = {
     "tdgl_set_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
     "tdgl_get_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
     "tdgl_induced_vector_potential": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_get_step_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.c_int32]),
     "tdgl_get_loop_state": (
         C.c_int,
         [_CTX, C.POINTER(C.c_int64), c_f64p, c_f64p, c_f64p],

@@ -48,6 +48,23 @@ class _HierarchyInfo:
         self.operator_complexity = operator_complexity if operator_complexity is not None else local.operator_complexity
 
 
+class _Stopwatch:
+    """Accumulates wall-clock seconds per set-up phase (``TDGLContext.setup_times``)."""
+
+    def __init__(self, table, name):
+        self.table, self.name = table, name
+
+    def __enter__(self):
+        import time
+
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+
+        self.table[self.name] = self.table.get(self.name, 0.0) + time.perf_counter() - self.t0
+
+
 class TDGLContext:
     """Owns one ``tdgl_ctx`` (device buffers + stream) for a mesh."""
 
@@ -58,6 +75,9 @@ class TDGLContext:
         _lib.require_gpu()
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
+        # seconds spent in the set-up phases: "reorder" (RCM), "upload" (tdgl_create and every operator
+        # upload), "amg_host" (aggregation, Galerkin products, collapsed / pre-multiplied operators)
+        self.setup_times = {}
         em = mesh.edge_mesh
         self.n = len(mesh.sites)
         self.m = len(em.edges)
@@ -68,7 +88,8 @@ class TDGLContext:
         if n_owned:
             reorder = None
         if reorder == "rcm":
-            perm = rcm_permutation(em.edges, self.n)
+            with _Stopwatch(self.setup_times, "reorder"):
+                perm = rcm_permutation(em.edges, self.n)
         elif reorder is None or reorder == "none":
             perm = np.arange(self.n, dtype=np.int32)
         else:
@@ -92,7 +113,8 @@ class TDGLContext:
             fix_psi=int(bool(fix_psi)), site_perm=None if n_owned else p_i32(perm), u=float(u),
             gamma=float(gamma), n_owned=int(n_owned),
         )
-        _lib.check(self._lib.tdgl_create(C.byref(self._ctx), C.byref(desc), int(device_id)))
+        with _Stopwatch(self.setup_times, "upload"):
+            _lib.check(self._lib.tdgl_create(C.byref(self._ctx), C.byref(desc), int(device_id)))
         self.hierarchy = None
 
     # -- lifetime ---------------------------------------------------------------------
@@ -120,8 +142,9 @@ class TDGLContext:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
         operators.py:305-308) + upload."""
         k = self._keep
-        A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
-        h = build_hierarchy(A, max_coarse=max_coarse)
+        with _Stopwatch(self.setup_times, "amg_host"):
+            A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
+            h = build_hierarchy(A, max_coarse=max_coarse)
         self._shipped_plan = None
         self.set_hierarchy(h)
         self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step,
@@ -256,7 +279,8 @@ class TDGLContext:
                 L.n_coarse = 0
             keep.append(arrs)
         pinv = f64(h.coarse_pinv)
-        self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
+        with _Stopwatch(self.setup_times, "upload"):
+            self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
         self.hierarchy = h
         self._hier_epoch = getattr(self, "_hier_epoch", 0) + 1
         self._refresh_fused_restriction()
@@ -272,11 +296,13 @@ class TDGLContext:
             if not on:
                 self._chk(self._lib.tdgl_poisson_set_fused_level(self._ctx, k, None, None, None, None, None, None, None))
                 continue
-            RA, AP, p_on_ap = fused_level_operators(h.levels[k])
+            with _Stopwatch(self.setup_times, "amg_host"):
+                RA, AP, p_on_ap = fused_level_operators(h.levels[k])
             a = [i32(RA.indptr), i32(RA.indices), f64(RA.data), i32(AP.indptr), i32(AP.indices), f64(AP.data),
                  f64(p_on_ap)]
-            self._chk(self._lib.tdgl_poisson_set_fused_level(
-                self._ctx, k, p_i32(a[0]), p_i32(a[1]), p_f64(a[2]), p_i32(a[3]), p_i32(a[4]), p_f64(a[5]), p_f64(a[6])))
+            with _Stopwatch(self.setup_times, "upload"):
+                self._chk(self._lib.tdgl_poisson_set_fused_level(
+                    self._ctx, k, p_i32(a[0]), p_i32(a[1]), p_f64(a[2]), p_i32(a[3]), p_i32(a[4]), p_f64(a[5]), p_f64(a[6])))
 
     def _refresh_fused_restriction(self):
         """(Re)build R0 (I - c A0 D0^-1) for the level-0 smoothing coefficient in use
@@ -286,21 +312,28 @@ class TDGLContext:
             return
         if o["nu_fine"] != 1 or not o.get("fused_restriction", True):
             self._chk(self._lib.tdgl_poisson_set_fused_restriction(self._ctx, 0, 0, None, None, None, 0.0))
+            self._fusedR_key = None
             return
         from .amg import fused_restriction, fused_restriction_from, smoother_coefficients
 
         name = "jacobi" if o["smoother"] == 0 else "chebyshev"
         c = smoother_coefficients(h.levels[0].rho, 1, name, o["cheb_lo"])[1][0]
         lv0 = getattr(self, "_local_level0", None)
-        if lv0 is not None:  # one process per GPU: this rank's slice in LOCAL numbering, ghost columns included
-            M = fused_restriction_from(lv0.A, lv0.R, lv0.dinv, c)
-        elif self.n_owned != self.n:
+        if lv0 is None and self.n_owned != self.n:
             return
-        else:
-            M = fused_restriction(h, c)
+        key = (getattr(self, "_hier_epoch", 0), float(c))
+        if getattr(self, "_fusedR_key", None) == key:  # already on the device for this hierarchy / coefficient
+            return
+        with _Stopwatch(self.setup_times, "amg_host"):
+            if lv0 is not None:  # one process per GPU: this rank's slice in LOCAL numbering, ghost columns included
+                M = fused_restriction_from(lv0.A, lv0.R, lv0.dinv, c)
+            else:
+                M = fused_restriction(h, c)
         ip, ix, dx = i32(M.indptr), i32(M.indices), f64(M.data)
-        self._chk(self._lib.tdgl_poisson_set_fused_restriction(
-            self._ctx, M.shape[0], M.shape[1], p_i32(ip), p_i32(ix), p_f64(dx), float(c)))
+        with _Stopwatch(self.setup_times, "upload"):
+            self._chk(self._lib.tdgl_poisson_set_fused_restriction(
+                self._ctx, M.shape[0], M.shape[1], p_i32(ip), p_i32(ix), p_f64(dx), float(c)))
+        self._fusedR_key = key
 
     def _refresh_collapsed(self):
         """(Re)build the collapsed coarse chain for the smoother settings in use
@@ -322,8 +355,9 @@ class TDGLContext:
                                                    o.get("tail_cycles", 2)):
             plan = shipped[1]  # built once by the root rank (distributed.prepare_payloads)
         else:
-            plan = collapsed_operators(h, o["nu"], name, o["cheb_lo"], tail_cycles=o.get("tail_cycles", 2)) \
-                if (o.get("collapse", True) and o["nu"] == 2) else None
+            with _Stopwatch(self.setup_times, "amg_host"):
+                plan = collapsed_operators(h, o["nu"], name, o["cheb_lo"], tail_cycles=o.get("tail_cycles", 2)) \
+                    if (o.get("collapse", True) and o["nu"] == 2) else None
         self.collapsed_plan = plan
         for k in range(1, len(h.levels) - 1):
             M = None if plan is None else plan["mid"].get(k)
@@ -538,6 +572,12 @@ class TDGLContext:
         A = np.empty((self.m, 2))
         self._chk(self._lib.tdgl_get_induced_vector_potential(self._ctx, p_f64(A)))
         return A
+
+    def step_stats(self, reset=False):
+        """``dict(steps, psi_retries, pcg_iterations, host_syncs)`` of `run` since the last reset."""
+        out = (C.c_int64 * 4)()
+        self._chk(self._lib.tdgl_get_step_stats(self._ctx, out, int(bool(reset))))
+        return dict(steps=out[0], psi_retries=out[1], pcg_iterations=out[2], host_syncs=out[3])
 
     def loop_state(self):
         step, t, rdt, tdt = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)

@@ -29,7 +29,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _problem(width=60, height=15):
+def _problem(width=60, height=15, dt_init=1e-4, dt_max=0.1, b=0.05):
     for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,12 +38,12 @@ def _problem(width=60, height=15):
 
     mesh = synthetic_mesh(width, height)
     terms = [edge_terminal(mesh, "source", -width / 2), edge_terminal(mesh, "drain", width / 2)]
-    A = uniform_field_A(mesh, 0.05)
+    A = uniform_field_A(mesh, b)
     em = mesh.edge_mesh
     mu_b = np.zeros(len(em.boundary_edge_indices))
     for t, sign in zip(terms, (1.0, -1.0)):
         mu_b[t["boundary_edge_indices"]] = sign * 6.0 / t["length"]
-    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=1000, pcg_rtol=1e-11)
+    opts = SolverOptions(solve_time=1e9, dt_init=dt_init, dt_max=dt_max, save_every=1000, pcg_rtol=1e-11)
     probes = [mesh.closest_site((-15, 0)), mesh.closest_site((15, 0))]
     fixed = np.concatenate([t["site_indices"] for t in terms])
     psi0 = np.ones(len(mesh.sites), dtype=complex)
@@ -51,9 +51,9 @@ def _problem(width=60, height=15):
     return mesh, terms, A, mu_b, opts, probes, psi0
 
 
-def _worker(rank, world, port, transport, out_dir, overlap=True, size=(60, 15)):
+def _worker(rank, world, port, transport, out_dir, overlap=True, size=(60, 15), problem_kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(*size)
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(*size, **(problem_kw or {}))
     from tdgl_amd import _lib  # noqa: F401  (load libtdgl_hip and its ROCm runtime before torch)
 
     _lib.load()
@@ -73,14 +73,15 @@ def _worker(rank, world, port, transport, out_dir, overlap=True, size=(60, 15)):
             on, rows = run.ctx.comm_overlap()
             np.savez(os.path.join(out_dir, f"dist_{transport}_{world}.npz"), dt=res["dt"], mu_probe=res["mu"],
                      theta_probe=res["theta"], iters=res["pcg_iters"], overlap=on, interior_rows=rows,
-                     n_own=run.lp.n_own, n_interior=run.lp.n_interior, **fields)
+                     n_own=run.lp.n_own, n_interior=run.lp.n_interior, gram=run.ctx.guess_gram(),
+                     retries=run.ctx.step_stats()["psi_retries"], **fields)
         run.close()
     finally:
         dist.destroy_process_group()
 
 
-def _single_gpu_reference(size=(60, 15)):
-    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(*size)
+def _single_gpu_reference(size=(60, 15), problem_kw=None, want_ctx=False):
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(*size, **(problem_kw or {}))
     from tdgl_amd import TDGLSolver
 
     cur = {"source": 6.0, "drain": -6.0}
@@ -92,6 +93,8 @@ def _single_gpu_reference(size=(60, 15)):
     ctx.set_state(psi0, np.zeros(len(mesh.sites)))
     ctx.begin_stage()
     res = ctx.run(N_STEPS)
+    if want_ctx:
+        return mesh, res, ctx.get_state(), ctx
     return mesh, res, ctx.get_state()
 
 
@@ -110,6 +113,30 @@ def test_multi_rank_run_matches_single_gpu(world, tmp_path):
     assert np.abs((got["mu_probe"][:, 0] - got["mu_probe"][:, 1]) - (ref_res["mu"][:, 0] - ref_res["mu"][:, 1])).max() < 1e-9
     # the decomposition must not change the iteration count materially
     assert abs(got["iters"].mean() - ref_res["pcg_iters"].mean()) < 2.0
+
+
+def test_projection_gram_stays_global_through_psi_retries(tmp_path):
+    """A psi update that fails abandons the mu solve after its first synchronisation and the step
+    calls the solver again (solver.py:475-485).  The projection guess's dot products are all-reduced
+    in place at that synchronisation; the entry that only the previous converged solve rewrites
+    (x_new . b_new) must be consumed the first time, not summed over the ranks twice.  Checked through
+    the Gram matrix G_ij = x_i . b_j itself -- a global quantity -- of a run with forced retries
+    (dt_init = dt_max = 2, b = 0.8: the reference's own retry fixture settings) on 2 ranks against
+    the single-GPU run."""
+    kw = dict(dt_init=2.0, dt_max=2.0, b=0.8)
+    mesh, ref_res, ref, ctx = _single_gpu_reference(problem_kw=kw, want_ctx=True)
+    assert ctx.step_stats()["psi_retries"] > 0
+    G = ctx.guess_gram()
+    mp.spawn(_worker, args=(2, _free_port(), "gloo", str(tmp_path), True, (60, 15), kw), nprocs=2, join=True)
+    got = np.load(os.path.join(tmp_path, "dist_gloo_2.npz"))
+    assert int(got["retries"]) == ctx.step_stats()["psi_retries"]
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
+    assert got["gram"].shape == G.shape and G.shape[0] >= 2
+    scale = np.sqrt(np.outer(np.abs(np.diag(G)), np.abs(np.diag(G)))) + 1e-300
+    filled = np.diag(G) != 0  # (the newest diagonal entry travels with the next status block)
+    assert filled.sum() >= G.shape[0] - 1
+    assert np.abs((got["gram"] - G) / scale)[np.ix_(filled, filled)].max() < 1e-6
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-8
 
 
 @pytest.mark.parametrize("overlap", [True, False])

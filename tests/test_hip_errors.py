@@ -138,3 +138,67 @@ def test_smallest_meshes_run(shape):
     assert abs(got["mu"].mean()) < 1e-12
     # total current is divergence free
     assert max_abs(divergence_matrix(mesh) @ (got["supercurrent"] + got["normal_current"]), 0 * rhs) < 1e-9
+
+
+def _small_transport_solver(probes=True):
+    from helpers import edge_terminal
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    mesh = synthetic_mesh(40, 12)
+    terms = [edge_terminal(mesh, "source", -20.0), edge_terminal(mesh, "drain", 20.0)]
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=10**9)
+    solver = TDGLSolver.from_dimensionless(
+        mesh, opts, uniform_field_A(mesh, 0.02), 1.0, U_DEFAULT, GAMMA_DEFAULT, terminal_info=terms,
+        current_func={"source": 3.0, "drain": -3.0},
+        probe_points=[mesh.closest_site((-10, 0)), mesh.closest_site((10, 0))] if probes else None,
+    )
+    solver.ctx.set_state(solver.psi_init, solver.mu_init)
+    solver.ctx.begin_stage()
+    solver.update_mu_boundary(0.0)
+    return mesh, solver
+
+
+def test_probe_ring_buffer_wraps_and_matches_short_batches():
+    """Probe read-outs (running state "mu" / "theta", solver.py:690-694) live in a device ring buffer of
+    1024 steps that `tdgl_run` flushes when it fills and when the batch ends: one call of 2,500 steps
+    must return the very trace that 25 calls of 100 steps return, and probes must not change a step."""
+    n_steps = 2500
+    mesh, one = _small_transport_solver()
+    a = one.ctx.run(n_steps)
+    assert a["mu"].shape == (n_steps, 2) and np.all(np.isfinite(a["mu"])) and np.all(np.isfinite(a["theta"]))
+    assert one.ctx.step_stats()["host_syncs"] <= 2 * n_steps + 3 + a["pcg_iters"].sum()  # flushes: 3, not 2,500
+    _, many = _small_transport_solver()
+    parts = [many.ctx.run(100) for _ in range(n_steps // 100)]
+    for key in ("dt", "mu", "theta"):
+        assert np.array_equal(a[key], np.concatenate([p[key] for p in parts])), key
+    st = one.ctx.get_state()
+    probes = [mesh.closest_site((-10, 0)), mesh.closest_site((10, 0))]
+    assert np.array_equal(a["mu"][-1], st["mu"][probes])
+    _, bare = _small_transport_solver(probes=False)
+    b = bare.ctx.run(n_steps)
+    assert b["mu"] is None and np.array_equal(b["dt"], a["dt"])
+    assert np.array_equal(bare.ctx.get_state()["psi"], st["psi"])
+
+
+def test_run_restarts_from_recorded_controller_state():
+    """`tdgl_get/set_controller_state` + `tdgl_set_loop_state` + `tdgl_set_state`: a run restarted from a
+    recorded point takes the dt sequence the uninterrupted run took (the list d_psi_sq_vals persists
+    in the reference, solver.py:318, 698-707)."""
+    _, s = _small_transport_solver()
+    ctx = s.ctx
+    ctx.run(137)
+    st, ls, cs = ctx.get_state(), ctx.loop_state(), ctx.controller_state()
+    assert len(cs["history"]) >= 10 and cs["tentative_dt"] == ls["tentative_dt"]
+    cont = ctx.run(60)
+    end = ctx.get_state()
+    _, t = _small_transport_solver()
+    t.ctx.set_state(st["psi"], st["mu"])
+    t.ctx.set_loop_state(ls["step"], ls["time"], ls["dt"])
+    t.ctx.set_controller_state(cs["tentative_dt"], cs["history"])
+    again = t.ctx.run(60)
+    assert max_abs(again["dt"], cont["dt"]) <= 1e-9 * cont["dt"].max()
+    got = t.ctx.get_state()
+    assert max_abs(np.abs(got["psi"]) ** 2, np.abs(end["psi"]) ** 2) < 1e-8
+    assert max_abs(remove_mean(got["mu"]), remove_mean(end["mu"])) < 1e-8 * max(1.0, np.abs(end["mu"]).max())
+    with pytest.raises(ValueError, match="tentative_dt must be positive"):
+        t.ctx.set_controller_state(0.0, [])

@@ -1,5 +1,9 @@
-"""GPU tests at BASELINE.json's configuration sizes, through size-independent properties
-(the oracle's LU cannot be afforded at these sizes inside a test, except where noted)."""
+"""GPU tests at BASELINE.json's configuration sizes: the stepped states through size-independent
+properties (the oracle's LU cannot be afforded at these sizes inside a test, except where noted), and
+every LU-free piece of the step -- `psi_laplacian @ psi`, `get_supercurrent`, the Poisson right-hand
+side, the normal current and a teacher-forced psi update -- against the oracle's NUMBERS on those
+states (`_values_match_the_oracle`).  Step-level parity at the headline size is taken by `bench.py`
+(`parity_vs_oracle`), where the LU has to be paid anyway."""
 
 import numpy as np
 import pytest
@@ -15,6 +19,44 @@ def _cut_current(mesh, js, jn, x0):
     cross = (xa < x0) != (xb < x0)
     sign = np.where(xa < x0, 1.0, -1.0)
     return float(((js + jn) * em.dual_edge_lengths * sign)[cross].sum())
+
+
+def _values_match_the_oracle(mesh, A, ctx, st, dt, fixed=None, mu_boundary=None, seed=0):
+    """The reference formulas evaluated by the oracle (SciPy matrices) against the HIP kernels on the
+    same inputs, 1e-12 relative to the largest entry of each result:
+    operators.py:120-185 (`psi_laplacian @ psi`, identity rows on `fixed`), :385-394 (`get_supercurrent`),
+    solver.py:507-510 (rhs), :519 (J_n), :383-439 (`solve_for_psi_squared`, teacher-forced)."""
+    from oracle import psi_update
+    from oracle.fv_operators import divergence_matrix, gradient_matrix, laplacian_matrix, neumann_boundary_matrix
+
+    n, em = len(mesh.sites), mesh.edge_mesh
+    psi, mu = st["psi"], st["mu"]
+    rng = np.random.default_rng(seed)
+    noise = rng.normal(size=n) + 1j * rng.normal(size=n)
+    lap, _ = laplacian_matrix(mesh, A, fixed_sites=fixed)
+    for f in (psi, noise):  # the stepped state, and a field with no smoothness to hide behind
+        want = lap @ f
+        assert max_abs(ctx.apply_psi_laplacian(f), want) <= 1e-12 * np.abs(want).max()
+    grad = gradient_matrix(mesh, A)
+    for f in (psi, noise):
+        want = (f.conjugate()[em.edges[:, 0]] * (grad @ f)).imag
+        assert max_abs(ctx.supercurrent(f), want) <= 1e-12 * max(1.0, np.abs(want).max())
+    js = (psi.conjugate()[em.edges[:, 0]] * (grad @ psi)).imag
+    rhs = divergence_matrix(mesh) @ js
+    if mu_boundary is not None:
+        rhs = rhs - neumann_boundary_matrix(mesh) @ mu_boundary
+    assert max_abs(ctx.poisson_rhs(psi), rhs) <= 1e-12 * max(1.0, np.abs(rhs).max())
+    jn = -(gradient_matrix(mesh) @ mu).real
+    assert max_abs(ctx.normal_current(mu), jn) <= 1e-12 * max(1.0, np.abs(jn).max())
+    assert max_abs(st["normal_current"], jn) <= 1e-12 * max(1.0, np.abs(jn).max())
+    assert max_abs(st["supercurrent"], js) <= 1e-12 * max(1.0, np.abs(js).max())
+    # one psi update from the stepped state with the step's own dt, and one with a dt that fails
+    want = psi_update(psi, np.abs(psi) ** 2, mu, np.ones(n), GAMMA_DEFAULT, U_DEFAULT, dt, lap)
+    got = ctx.psi_update(psi, mu, dt)
+    assert want is not None and got is not None
+    assert max_abs(got[0], want[0]) <= 1e-12 and max_abs(got[1], want[1]) <= 1e-12
+    assert (ctx.psi_update(noise, mu, 50.0) is None) == (psi_update(noise, np.abs(noise) ** 2, mu, np.ones(n), GAMMA_DEFAULT,
+                                                                    U_DEFAULT, 50.0, lap) is None)
 
 
 def test_config4_strip_500k_current_conservation_and_poisson_residual():
@@ -60,6 +102,14 @@ def test_config4_strip_500k_current_conservation_and_poisson_residual():
     assert np.abs(st["psi"]).max() < 1.0 + 1e-9
     # (4) voltage has the sign of the current
     assert res["mu"][-1, 0] - res["mu"][-1, 1] > 0
+    # (5) the probe trace of the batch (device ring buffer, flushed once) is the state's own mu / arg psi
+    assert np.array_equal(res["mu"][-1], st["mu"][probes]) and max_abs(res["theta"][-1], np.angle(st["psi"][probes])) < 1e-14
+    assert np.all(np.isfinite(res["mu"])) and np.all(res["mu"][1:, 0] - res["mu"][1:, 1] > 0)
+    # (6) values against the oracle's formulas on this state
+    mu_b = np.zeros(len(em.boundary_edge_indices))
+    for t, sign in zip(terms, (+1.0, -1.0)):  # solver.py:336-345: J_i = -(1 / L_i) sum_{j != i} I_j
+        mu_b[t["boundary_edge_indices"]] = sign * current / t["length"]
+    _values_match_the_oracle(mesh, uniform_field_A(mesh, 0.0), ctx, st, float(res["dt"][-1]), fixed=fixed, mu_boundary=mu_b)
 
 
 def test_config2_250k_uniform_field_first_steps_match_oracle():
@@ -142,3 +192,5 @@ def test_config3_and_5_steps_satisfy_their_defining_equations(side, n_sites, ste
     assert max_abs(got["normal_current"], -(gradient_matrix(mesh) @ got["mu"])) < 1e-11 * max(1.0, np.abs(got["mu"]).max())
     assert max_abs(div @ (got["supercurrent"] + got["normal_current"]), 0 * rhs) < 1e-8 * scale
     assert abs(got["mu"].mean()) < 1e-11 * max(1.0, np.abs(got["mu"]).max())
+    del div, lap
+    _values_match_the_oracle(mesh, uniform_field_A(mesh, 0.1), ctx, got, float(res["dt"][-1]))
