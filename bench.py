@@ -50,10 +50,13 @@ WORKLOADS = {
     "4M": (1860.0, "square film 1860 xi, 3,998,502 sites"),
     # BASELINE config 4: strip with two current terminals (short edges), I = 0.2 * Ly, zero field
     "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly"),
-    # the same strip driven above the depairing current density (2 / (3 sqrt 3) = 0.385 in these units): phase slips
-    "strip500k_ps": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.45 Ly (above the critical current: phase slips)"),
+    # the same strip just above the depairing current density (2 / (3 sqrt 3) = 0.385 in these units)
+    "strip500k_ps": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.39 Ly (just above the depairing current)"),
+    # ... and in a perpendicular field with the sub-critical current: vortices enter at the long edges and are driven across (flux flow)
+    "strip500k_ff": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly, uniform field b = 0.02 (flux flow)"),
 }
-STRIP_CURRENT = {"strip500k": 0.2, "strip500k_ps": 0.45}
+STRIP_CURRENT = {"strip500k": 0.2, "strip500k_ps": 0.39, "strip500k_ff": 0.2}
+STRIP_FIELD = {"strip500k": 0.0, "strip500k_ps": 0.0, "strip500k_ff": 0.02}
 B_FIELD = 0.1  # B / Bc2
 
 
@@ -187,7 +190,7 @@ def build_workload(name):
     mesh = Mesh.from_triangulation(pts, triangulate(pts))
     n, m = len(mesh.sites), len(mesh.edge_mesh.edges)
     log(f"workload {name}: mesh {n} sites / {m} edges in {time.perf_counter() - t0:.1f} s")
-    A = uniform_A(mesh, 0.0 if strip else B_FIELD)
+    A = uniform_A(mesh, STRIP_FIELD[name] if strip else B_FIELD)
     terms, currents = (), None
     if strip:
         em_ = mesh.edge_mesh
