@@ -123,6 +123,12 @@ typedef struct {
                              are stored in IEEE binary16 -- same PCG iteration count; falls back
                              to 1 when an entry exceeds binary16's range.  0: everything fp64.  */
     int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..8 (0 = 6)   */
+    int32_t flexible_cg;  /* 1 (default): beta = z_{k+1}.(r_{k+1} - r_k) / z_k.r_k (Polak-Ribiere, the
+                             "flexible" CG), which tolerates a preconditioner that is not exactly
+                             symmetric -- the V-cycle's operators are rounded to fp32 / binary16
+                             one by one.  0: beta = z_{k+1}.r_{k+1} / z_k.r_k (Fletcher-Reeves).
+                             Single-GPU recurrence only; the one-reduction CG of the decomposed
+                             run keeps the Fletcher-Reeves beta with fp32-stored operators      */
 } tdgl_poisson_options;
 
 /* ------------------------------------------------------------------ lifetime */

@@ -133,7 +133,8 @@ struct AmgLevel {
 // arguments and a pair of iterations can be replayed as a hipGraph)
 // (S_CG_*: r.z and alpha of the previous iteration for the single-reduction CG, ping-pong by parity)
 // (S_RR0: ||r_0||^2 of the current solve, recorded by the first update: the quality of the initial guess)
-enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_CG_RZ0, S_CG_RZ1, S_CG_ALPHA0, S_CG_ALPHA1, S_RR0, S_COUNT = 12 };
+// (S_ALPHA: alpha of the last CG update, read by the next direction update's flexible beta)
+enum Scal { S_RR = 0, S_BB, S_CONV_IT, S_IT, S_TOL2, S_CG_RZ0, S_CG_RZ1, S_CG_ALPHA0, S_CG_ALPHA1, S_RR0, S_ALPHA, S_COUNT = 12 };
 
 // what a step reports back to the host at its synchronisation point
 // arguments of the CG update x += alpha p, r -= alpha q (kernels.inc: xr_update_body)
@@ -287,7 +288,7 @@ struct tdgl_ctx {
     // took it along
     bool xr_active = false, xr_carried = false;
     tdgl::XrArgs xr{};
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6, 1};
     // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
     // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
     // step's status block

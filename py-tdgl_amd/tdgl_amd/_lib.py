@@ -108,6 +108,7 @@ class PoissonOptions(C.Structure):
         ("nu_fine", C.c_int32),
         ("precond_fp32", C.c_int32),
         ("guess_window", C.c_int32),
+        ("flexible_cg", C.c_int32),
     ]
 
 

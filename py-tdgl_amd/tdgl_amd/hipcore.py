@@ -394,7 +394,7 @@ class TDGLContext:
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
                             extrapolate=3, nu_fine=1, fused_restriction=True, precond_fp32=True,
-                            collapse=True, tail_cycles=2, guess_window=6):
+                            collapse=True, tail_cycles=2, guess_window=6, flexible_cg=True):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         # storage of the V-cycle's operators: False / 0 fp64, 1 fp32, True / 2 fp32 + binary16 on level 0
         from .options import precond_storage_mode
@@ -402,13 +402,13 @@ class TDGLContext:
         precond_fp32 = precond_storage_mode(precond_fp32)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
-                                int(extrapolate), int(nu_fine), precond_fp32, int(guess_window))
+                                int(extrapolate), int(nu_fine), precond_fp32, int(guess_window), int(bool(flexible_cg)))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
                                     fused_restriction=bool(fused_restriction), precond_fp32=precond_fp32,
                                     edge_currents_every_step=bool(edge_currents_every_step),
                                     collapse=bool(collapse), tail_cycles=int(tail_cycles),
-                                    guess_window=int(guess_window))
+                                    guess_window=int(guess_window), flexible_cg=bool(flexible_cg))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
         self._refresh_fused_restriction()
         self._refresh_collapsed()

@@ -732,6 +732,72 @@ def test_strongly_irregular_mesh_matches_oracle():
     assert ctx.precond_storage() == 2  # binary16 level-0 operators, weights spread over four decades
 
 
+def _graded_ring_mesh(r0=0.02, r1=12.0, per_ring=96):
+    """Disk meshed by concentric rings whose spacing grows geometrically with the radius (alternate
+    rings rotated by half a step: near-equilateral triangles at every scale): edge lengths span
+    r1 / r0 = 600 : 1, site areas seven decades -- the refinement towards a point that
+    `make_mesh(max_edge_length=...)` users build around a defect or a constriction."""
+    from tdgl_amd.finite_volume import Mesh
+    from tdgl_amd.meshgen import triangulate
+
+    q = 1 + 0.9 * 2 * np.pi / per_ring
+    radii = r0 * q ** np.arange(int(np.log(r1 / r0) / np.log(q)) + 1)
+    rings = [np.zeros((1, 2))]
+    for k, r in enumerate(radii):
+        th = 2 * np.pi * (np.arange(per_ring) + 0.5 * (k % 2)) / per_ring
+        rings.append(np.column_stack([r * np.cos(th), r * np.sin(th)]))
+    pts = np.vstack(rings)
+    return Mesh.from_triangulation(pts, triangulate(pts))
+
+
+def test_graded_mesh_binary16_preconditioner_and_flexible_cg():
+    """Preconditioner safety on a graded mesh (edge ratio > 100 : 1) with the binary16 level-0 storage
+    active: the V-cycle's operators are rounded one by one, so it is no longer exactly symmetric; the
+    CG's flexible (Polak-Ribiere) beta is the default there.  Same solution as with fp64 storage, no
+    restart with the fp64 operators, iteration count within one of the fp64-stored cycle -- for the
+    flexible and for the Fletcher-Reeves beta -- and 25 adaptive steps against the oracle."""
+    from oracle import OracleSolver, run_time_loop
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    mesh = _graded_ring_mesh()
+    em = mesh.edge_mesh
+    assert len(mesh.sites) > 10000 and em.edge_lengths.max() / em.edge_lengths.min() > 100 and em.dual_edge_lengths.min() > 0
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-5, dt_max=1e-1, save_every=10**9, pcg_rtol=1e-11)
+    A = uniform_field_A(mesh, 0.3)
+    solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0, U_DEFAULT, GAMMA_DEFAULT)
+    ctx = solver.ctx
+    rng = np.random.default_rng(3)
+    rhs = rng.normal(size=ctx.n) / np.sqrt(mesh.areas)
+    rhs -= (rhs * mesh.areas).sum() / mesh.areas.sum()
+    base = dict(rtol=1e-11, max_iter=200, extrapolate=3)
+    runs = {}
+    for name, kw in (("fp64", dict(precond_fp32=False)), ("f16_flexible", dict(precond_fp32=True, flexible_cg=True)),
+                     ("f16_fletcher_reeves", dict(precond_fp32=True, flexible_cg=False))):
+        ctx.set_poisson_options(**base, **kw)
+        mu, iters, relres = ctx.poisson_solve(rhs)
+        runs[name] = (mu, iters)
+        assert relres <= 1e-11
+        assert ctx.precond_storage() == (0 if name == "fp64" else 2), name
+    assert ctx.poisson_stats()["fp64_fallbacks"] == 0
+    scale = np.abs(runs["fp64"][0]).max()
+    for name in ("f16_flexible", "f16_fletcher_reeves"):
+        assert max_abs(runs[name][0], runs["fp64"][0]) < 1e-8 * scale, name
+        assert runs[name][1] <= runs["fp64"][1] + 1, (name, runs[name][1], runs["fp64"][1])
+    # ... and the time loop on it (default options: binary16 storage + flexible beta)
+    ctx.set_poisson_options(**base, precond_fp32=True)
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    res = ctx.run(25)
+    got = ctx.get_state()
+    want = run_time_loop(OracleSolver(mesh, A, 1.0, U_DEFAULT, GAMMA_DEFAULT, opts), opts, max_steps=25)
+    assert max_abs(res["dt"], want["log"].array("dt").ravel()) <= 1e-9 * res["dt"].max()
+    assert max_abs(np.abs(got["psi"]) ** 2, np.abs(want["psi"]) ** 2) < 1e-9
+    scale = max(1.0, np.abs(remove_mean(want["mu"])).max())
+    assert max_abs(remove_mean(got["mu"]), remove_mean(want["mu"])) < 1e-8 * scale
+    assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-8
+    assert ctx.precond_storage() == 2 and ctx.poisson_stats()["fp64_fallbacks"] == 0
+
+
 @pytest.mark.parametrize("lx, ly", [(1.0, 1.0), (2.0, 1.0), (3.0, 2.0), (6.0, 4.0), (9.0, 7.0), (30.0, 21.0)])
 def test_very_small_meshes_match_oracle(lx, ly):
     """Ragged and degenerate sizes: 5 to ~800 sites -- fewer rows than a wavefront, a single SELL slice,

@@ -8,7 +8,7 @@ for V in "$@"; do
   # "ENV=1 OTHER=2 @ --args": environment assignments before the @
   E=""; A="$V"
   case "$V" in *@*) E="${V%%@*}"; A="${V#*@}";; esac
-  timeout 900 env $E python bench.py --no-cpu-baseline $A > $OUT/ab_tmp.json 2> $OUT/ab_${TAG}_last.err || { echo "FAILED: $V"; tail -5 $OUT/ab_${TAG}_last.err; }
+  timeout 900 env $E python bench.py --no-cpu-baseline --vortex-window off $A > $OUT/ab_tmp.json 2> $OUT/ab_${TAG}_last.err || { echo "FAILED: $V"; tail -5 $OUT/ab_${TAG}_last.err; }
   python - "$V" <<'PY' >> $OUT/AB_${TAG}.jsonl
 import json,sys
 try:
