@@ -85,12 +85,16 @@ def _reference_hull_areas(areas, which, sites, elements, cc, edges, boundary_edg
     bedges = edges[boundary_edge_indices]
     which_set = np.zeros(len(sites), dtype=bool)
     which_set[which] = True
-    # incident triangles of the requested sites
-    tri_of = {int(i): [] for i in which}
-    for t, tri in enumerate(elements):
-        for v in tri:
-            if which_set[v]:
-                tri_of[int(v)].append(t)
+    # incident triangles of the requested sites (triangle ids grouped by site, ascending like the
+    # reference's scan over the elements)
+    hit = which_set[elements]                      # (t, 3)
+    t_idx, _ = np.nonzero(hit)
+    v_idx = elements[hit]
+    order = np.argsort(v_idx, kind="stable")
+    v_sorted, t_sorted = v_idx[order], t_idx[order]
+    starts = np.searchsorted(v_sorted, which)
+    stops = np.searchsorted(v_sorted, which, side="right")
+    tri_of = {int(i): t_sorted[a:b] for i, a, b in zip(which, starts, stops)}
     for i in which:
         poly = cc[tri_of[int(i)]]
         if not is_boundary[i]:
@@ -231,8 +235,8 @@ class Mesh:
             side = np.sign(((r - p) * nrm).sum(axis=1))
             h = ((cc - mid) * nrm).sum(axis=1) * side
             contrib = 0.25 * length * h
-            np.add.at(areas, elements[:, ip], contrib)
-            np.add.at(areas, elements[:, iq], contrib)
+            areas += np.bincount(elements[:, ip], weights=contrib, minlength=n)
+            areas += np.bincount(elements[:, iq], weights=contrib, minlength=n)
             # a circumcentre on the far side of its edge: the cell of both end sites needs the
             # reference's hull-based construction (below)
             neg = h < -1e-14 * length
