@@ -370,6 +370,11 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
     ctx->psi_blocks = (int)std::min<int64_t>(std::max<int64_t>(grid_for(ctx->n_own), 1), 2048);
+    {
+        const int64_t tiles = (ctx->n_own + BLOCK - 1) / BLOCK;
+        ctx->npart = (int)std::min<int64_t>(NB, std::max<int64_t>(1, (tiles + XCDS - 1) / XCDS) * XCDS);
+        if (ctx->n_own < ctx->n || getenv("TDGL_FULL_PARTIALS")) ctx->npart = NB;  // (environment switch: A/B measurements)
+    }
     HIP_TRY(ctx, ctx->psi_dmax_part.alloc(ctx->psi_blocks));
     HIP_TRY(ctx, ctx->psi_fail_part.alloc(ctx->psi_blocks));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
@@ -500,7 +505,7 @@ static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
                        ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
                        guess_start ? ctx->part_gdot.p : (const double *)nullptr, (double)ctx->n_global,
-                       ctx->popt.rtol * ctx->popt.rtol, rr_part);
+                       ctx->popt.rtol * ctx->popt.rtol, rr_part, ctx->npart);
     ctx->psi_status_pending = false;
 }
 

@@ -142,6 +142,7 @@ struct XrArgs {
     const double *p, *q, *part_rz, *part_pq, *part_rr_in;
     double *scal, *x, *r, *part_rr_out;
     int64_t n;
+    int npart;  // entries of every partial array in use (tdgl_ctx::npart)
 };
 
 constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels.inc: GK)
@@ -278,6 +279,10 @@ struct tdgl_ctx {
     double tail_cheb_lo = 0.0;
     tdgl::DevBuf<double> pcg_r, pcg_p, pcg_q;
     tdgl::DevBuf<double> pcg_p2;          // second direction buffer (fused direction update, k_sell_axp)
+    // Per-workgroup partials of the dot products: arrays of stride NB of which the first `npart` entries
+    // are written and summed -- the number of 256-row tiles rounded up to a multiple of 8, at most NB
+    // (NB itself in one-process-per-GPU mode, where the arrays are summed over ranks of different sizes)
+    int npart = 1024;
     tdgl::DevBuf<double> part_pair[2];    // 2 x NB partials each: [r.z | ||r||^2], ping-pong
     tdgl::DevBuf<double> part_pq, part_tmp;  // NB per-workgroup partials each
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
