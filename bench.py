@@ -594,6 +594,8 @@ def main():
         step_aggregate=main_line["step_aggregate"],
         # what a step costs the host: synchronisations and repeated psi updates in the timed window
         host=dict(syncs_per_step=round(r.work["host_syncs"] / max(r.work["steps"], 1), 2), psi_retries=int(r.work["psi_retries"]),
+                  # share of the timed window the host spent blocked waiting for the GPU (the rest: enqueueing)
+                  blocked_frac=round(r.work["host_wait_s"] / max(r.work["run_s"], 1e-12), 3),
                   probes=0 if (r.wl is None or r.wl.probes is None or args.no_probes) else len(r.wl.probes)),
         # seconds before the first step (not in `value`): meshing, RCM, AMG set-up on the host, uploads
         setup_s=r.setup,

@@ -372,9 +372,10 @@ int tdgl_run(tdgl_ctx *ctx, int64_t max_steps, double end_time, double *out_dt,
              double *out_mu_probe, double *out_theta_probe, int32_t *out_pcg_iters,
              int64_t *steps_done, int32_t *reached_end, int32_t *out_screening_iters);
 
-/* Work counters of tdgl_run since the last reset: out4 = {steps accepted, psi updates that failed and
- * were repeated with a smaller dt (solver.py:475-485), PCG iterations, host synchronisations}. */
-int tdgl_get_step_stats(tdgl_ctx *ctx, int64_t *out4, int32_t reset);
+/* Work counters of tdgl_run since the last reset: out6 = {steps accepted, psi updates that failed and
+ * were repeated with a smaller dt (solver.py:475-485), PCG iterations, host synchronisations,
+ * nanoseconds the host was blocked in them, nanoseconds inside tdgl_run}. */
+int tdgl_get_step_stats(tdgl_ctx *ctx, int64_t *out6, int32_t reset);
 
 /* Loop state: stage step index i, Runner.time, Runner.dt (state["dt"] of the next
  * iteration), tentative_dt of the controller. */

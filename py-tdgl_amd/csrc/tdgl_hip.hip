@@ -538,6 +538,10 @@ static int update_link_scale(tdgl_ctx *ctx, double scale, double dt_prev);  // b
 static int apply_time_tables(tdgl_ctx *ctx);                                 // below
 static int profile_event(tdgl_ctx *ctx, hipEvent_t *ev);                     // below
 
+static inline int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 #include "comm.inc"
 #include "poisson.inc"
 #include "screening.inc"

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -335,6 +336,7 @@ struct tdgl_ctx {
     // counters since the last reset (tdgl_get_step_stats): steps accepted, failed psi updates that were
     // repeated with a smaller dt, PCG iterations, host synchronisations inside tdgl_run
     int64_t stat_steps = 0, stat_psi_retries = 0, stat_pcg_iters = 0, stat_host_syncs = 0;
+    int64_t stat_wait_ns = 0, stat_run_ns = 0;  // host time blocked in those synchronisations / inside tdgl_run
 
     // ---- screening (screening.inc) -------------------------------------------------------
     bool scr_enabled = false;

@@ -235,8 +235,11 @@ class Mesh:
             side = np.sign(((r - p) * nrm).sum(axis=1))
             h = ((cc - mid) * nrm).sum(axis=1) * side
             contrib = 0.25 * length * h
-            areas += np.bincount(elements[:, ip], weights=contrib, minlength=n)
-            areas += np.bincount(elements[:, iq], weights=contrib, minlength=n)
+            # (np.add.at, not bincount + add: the summation order decides the last bit of an area, and the
+            # reference's LU of the singular Neumann matrix -- the oracle's too -- lives on those bits on
+            # tiny meshes, tests/test_hip_parity.py::test_very_small_meshes_match_oracle)
+            np.add.at(areas, elements[:, ip], contrib)
+            np.add.at(areas, elements[:, iq], contrib)
             # a circumcentre on the far side of its edge: the cell of both end sites needs the
             # reference's hull-based construction (below)
             neg = h < -1e-14 * length

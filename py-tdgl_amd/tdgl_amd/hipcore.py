@@ -574,10 +574,12 @@ class TDGLContext:
         return A
 
     def step_stats(self, reset=False):
-        """``dict(steps, psi_retries, pcg_iterations, host_syncs)`` of `run` since the last reset."""
-        out = (C.c_int64 * 4)()
+        """``dict(steps, psi_retries, pcg_iterations, host_syncs, host_wait_s, run_s)`` of `run` since the
+        last reset (``host_wait_s``: time blocked in the synchronisations; ``run_s``: time inside `run`)."""
+        out = (C.c_int64 * 6)()
         self._chk(self._lib.tdgl_get_step_stats(self._ctx, out, int(bool(reset))))
-        return dict(steps=out[0], psi_retries=out[1], pcg_iterations=out[2], host_syncs=out[3])
+        return dict(steps=out[0], psi_retries=out[1], pcg_iterations=out[2], host_syncs=out[3],
+                    host_wait_s=out[4] * 1e-9, run_s=out[5] * 1e-9)
 
     def loop_state(self):
         step, t, rdt, tdt = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
