@@ -1134,8 +1134,12 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
         TDGL_FAIL(ctx, TDGL_ERR_NOT_READY, "tdgl_time_kernel: no AMG hierarchy");
     DevBuf<double2> tmp_c;
     DevBuf<double> tmp_r, tmp_r2;
+    DevBuf<unsigned> bar_cnt;
+    DevBuf<int> bar_err;
+    HIP_TRY(ctx, bar_cnt.alloc(1));
+    HIP_TRY(ctx, bar_err.alloc(32));
     HIP_TRY(ctx, tmp_c.alloc(ctx->n_pad));
-    HIP_TRY(ctx, tmp_r.alloc(std::max(ctx->n_pad, ctx->m_pad)));
+    HIP_TRY(ctx, tmp_r.alloc(std::max<int64_t>(std::max(ctx->n_pad, ctx->m_pad), 256 * BLOCK)));
     HIP_TRY(ctx, tmp_r2.alloc(std::max(ctx->n_pad, ctx->m_pad)));
     const double2 *psi = ctx->psi[ctx->cur].p;
     auto once = [&]() -> int {
@@ -1166,6 +1170,30 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
                 hipLaunchKernelGGL(k_copy_d2, dim3(1), dim3(BLOCK), 0, ctx->stream, 64, psi, tmp_c.p);
                 hipLaunchKernelGGL(k_copy_d2, dim3(1), dim3(BLOCK), 0, ctx->stream, 64, psi, tmp_c.p + 64);
                 break;
+            case 10: case 11: case 12: case 13: case 14: case 15: {
+                // 100 device-wide barriers inside one launch (k_barrier_bench): 10 / 11 grid.sync() with 32 /
+                // 256 workgroups; 12 / 13 counter + agent-scope fences with 32 / 256; 14 the 32 workgroups
+                // of one XCD (every 8th of 256) with agent-scope fences; 15 the same with L2-local fences
+                const int mode = kernel <= 11 ? 0 : (kernel <= 14 ? 1 : 2);
+                int stride = kernel >= 14 ? 8 : 1;
+                const int grid = (kernel == 10 || kernel == 12) ? 32 : 256;
+                int iters = 100, workers = grid / stride;
+                (void)hipMemsetAsync(bar_cnt.p, 0, sizeof(unsigned), ctx->stream);
+                unsigned *cnt = bar_cnt.p;
+                double *data = tmp_r.p;
+                int *err = bar_err.p;
+                if (mode == 0) {
+                    void *args[] = {&iters, &stride, &workers, &cnt, &data, &err};
+                    if (hipLaunchCooperativeKernel(reinterpret_cast<void *>(k_barrier_bench<0>), dim3(grid), dim3(BLOCK), args, 0,
+                                                   ctx->stream) != hipSuccess)
+                        return TDGL_ERR_HIP;
+                } else if (mode == 1) {
+                    hipLaunchKernelGGL(k_barrier_bench<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, iters, stride, workers, cnt, data, err);
+                } else {
+                    hipLaunchKernelGGL(k_barrier_bench<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, iters, stride, workers, cnt, data, err);
+                }
+                break;
+            }
             default: return TDGL_ERR_ARG;
         }
         return TDGL_OK;
@@ -1181,6 +1209,14 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms = (double)ms / reps;
+    if (kernel >= 10 && kernel <= 15) {  // stale reads, block -> XCD mapping: reported through the error string
+        int h[17] = {0};
+        HIP_TRY(ctx, hipMemcpy(h, bar_err.p, sizeof(h), hipMemcpyDeviceToHost));
+        char buf[256];
+        int off = snprintf(buf, sizeof(buf), "barrier bench %d: stale reads %d; XCC_ID of blocks 0-15:", kernel, h[0]);
+        for (int b = 0; b < 16 && off < (int)sizeof(buf) - 4; ++b) off += snprintf(buf + off, sizeof(buf) - off, " %d", h[1 + b]);
+        ctx->err = buf;
+    }
     ctx->psi_status_pending = false;  // (the psi-update kernel may have run on scratch data)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TDGL_OK;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
