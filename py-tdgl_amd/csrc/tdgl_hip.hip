@@ -475,6 +475,23 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
     const int per_xcd = (tiles + XCDS - 1) / XCDS, grid = per_xcd * XCDS;
     const SellPattern &pat = ctx->lap_pat;
     const double *c = rhs ? ctx->ceff.p : ctx->cvec.p;
+    // single GPU, all tiles: the software-pipelined kernel on a fixed grid (k_psi_laplacian_pipe); K1_WGS
+    // workgroups per CU (measured best), 0 = the one-slice-per-wave kernel
+    static const int k1_wgs = getenv("TDGL_K1_WGS") ? atoi(getenv("TDGL_K1_WGS")) : 3;
+    if (part == 0 && k1_wgs > 0 && tiles > 256 * k1_wgs) {
+        const int pgrid = 256 * k1_wgs;
+#define TDGL_K1P(RHS, IT, COLS)                                                                                  \
+    hipLaunchKernelGGL((k_psi_laplacian_pipe<RHS, IT>), dim3(pgrid), dim3(BLOCK), 0, ctx->stream, slice_end,     \
+                       per_xcd, pat.n_rows, pat.slice_off.p, COLS, ctx->lap_vals.p, ctx->lap_diag.p,            \
+                       ctx->fixed_mask.p, psi, lap, ctx->area.p, c, ctx->bvec.p)
+        if (pat.use16) {
+            if (rhs) TDGL_K1P(true, int16_t, pat.cols16.p); else TDGL_K1P(false, int16_t, pat.cols16.p);
+        } else {
+            if (rhs) TDGL_K1P(true, int32_t, pat.cols.p); else TDGL_K1P(false, int32_t, pat.cols.p);
+        }
+#undef TDGL_K1P
+        return;
+    }
 #define TDGL_K1(RHS, IT, COLS)                                                                              \
     hipLaunchKernelGGL((k_psi_laplacian<RHS, IT>), dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd, \
                        tile_base, pat.n_rows, pat.slice_off.p, COLS, ctx->lap_vals.p, ctx->lap_diag.p,     \
