@@ -475,23 +475,6 @@ static void launch_psi_laplacian(tdgl_ctx *ctx, bool rhs, const double2 *psi, do
     const int per_xcd = (tiles + XCDS - 1) / XCDS, grid = per_xcd * XCDS;
     const SellPattern &pat = ctx->lap_pat;
     const double *c = rhs ? ctx->ceff.p : ctx->cvec.p;
-    // single GPU, all tiles: the software-pipelined kernel on a fixed grid (k_psi_laplacian_pipe); K1_WGS
-    // workgroups per CU (measured best), 0 = the one-slice-per-wave kernel
-    static const int k1_wgs = getenv("TDGL_K1_WGS") ? atoi(getenv("TDGL_K1_WGS")) : 3;
-    if (part == 0 && k1_wgs > 0 && tiles > 256 * k1_wgs) {
-        const int pgrid = 256 * k1_wgs;
-#define TDGL_K1P(RHS, IT, COLS)                                                                                  \
-    hipLaunchKernelGGL((k_psi_laplacian_pipe<RHS, IT>), dim3(pgrid), dim3(BLOCK), 0, ctx->stream, slice_end,     \
-                       per_xcd, pat.n_rows, pat.slice_off.p, COLS, ctx->lap_vals.p, ctx->lap_diag.p,            \
-                       ctx->fixed_mask.p, psi, lap, ctx->area.p, c, ctx->bvec.p)
-        if (pat.use16) {
-            if (rhs) TDGL_K1P(true, int16_t, pat.cols16.p); else TDGL_K1P(false, int16_t, pat.cols16.p);
-        } else {
-            if (rhs) TDGL_K1P(true, int32_t, pat.cols.p); else TDGL_K1P(false, int32_t, pat.cols.p);
-        }
-#undef TDGL_K1P
-        return;
-    }
 #define TDGL_K1(RHS, IT, COLS)                                                                              \
     hipLaunchKernelGGL((k_psi_laplacian<RHS, IT>), dim3(grid), dim3(BLOCK), 0, ctx->stream, slice_end, per_xcd, \
                        tile_base, pat.n_rows, pat.slice_off.p, COLS, ctx->lap_vals.p, ctx->lap_diag.p,     \
@@ -1153,6 +1136,8 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
     DevBuf<double> tmp_r, tmp_r2;
     DevBuf<unsigned> bar_cnt;
     DevBuf<int> bar_err;
+    DevBuf<double2> big;
+    if (kernel >= 16 && kernel <= 20) HIP_TRY(ctx, big.alloc((size_t)1 << 26));  // 1 GiB
     HIP_TRY(ctx, bar_cnt.alloc(1));
     HIP_TRY(ctx, bar_err.alloc(32));
     HIP_TRY(ctx, tmp_c.alloc(ctx->n_pad));
@@ -1211,6 +1196,26 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
                 }
                 break;
             }
+            case 16:  // read-only stream over 1 GiB (HBM-cold: four times the Infinity Cache)
+                hipLaunchKernelGGL(k_stream_read<4>, dim3(256 * 8), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n, (const double2 *)big.p,
+                                   tmp_r.p);
+                break;
+            case 18:  // ... 8 loads per lane in flight
+                hipLaunchKernelGGL(k_stream_read<8>, dim3(256 * 8), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n, (const double2 *)big.p,
+                                   tmp_r.p);
+                break;
+            case 19:  // ... 16 workgroups per CU
+                hipLaunchKernelGGL(k_stream_read<4>, dim3(256 * 16), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n, (const double2 *)big.p,
+                                   tmp_r.p);
+                break;
+            case 20:  // ... one pass, no loop: a workgroup per 256 x 2 entries
+                hipLaunchKernelGGL(k_stream_read<2>, dim3((unsigned)(big.n / (BLOCK * 2))), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n,
+                                   (const double2 *)big.p, tmp_r.p);
+                break;
+            case 17:  // copy 512 MiB -> 512 MiB
+                hipLaunchKernelGGL(k_stream_copy<4>, dim3(256 * 8), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n / 2,
+                                   (const double2 *)big.p, big.p + big.n / 2);
+                break;
             default: return TDGL_ERR_ARG;
         }
         return TDGL_OK;

@@ -28,3 +28,9 @@ for k, name in names.items():
         print(f"id {k} {name}: {per:.2f} us per barrier   [{msg}]", flush=True)
     except Exception as exc:  # noqa: BLE001
         print(f"id {k} {name}: FAILED {exc}", flush=True)
+gib = 2.0**30
+print("HBM-cold streaming ceilings (1 GiB working set):")
+ms = ctx.time_kernel(16, 20); print(f"  read-only: {gib / (ms * 1e-3) / 1e12:.2f} TB/s ({ms * 1e3:.1f} us per GiB)")
+ms = ctx.time_kernel(17, 20); print(f"  copy (512 MiB -> 512 MiB): {gib / (ms * 1e-3) / 1e12:.2f} TB/s moved")
+for k, name in ((18, "read-only, 8 loads per lane in flight"), (19, "read-only, 16 workgroups per CU"), (20, "read-only, one workgroup per 512 entries")):
+    ms = ctx.time_kernel(k, 20); print(f"  {name}: {gib / (ms * 1e-3) / 1e12:.2f} TB/s")
