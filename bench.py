@@ -276,8 +276,8 @@ def main():
                     help="keep the level-0 operators of the V-cycle in fp64 (default: fp32 storage inside the fp64 CG)")
     ap.add_argument("--precond-fp32", action="store_true",
                     help="fp32 storage only (default: fp32 and, for the three level-0 operator streams, binary16)")
-    ap.add_argument("--cg-fr", action="store_true",
-                    help="Fletcher-Reeves beta in the CG (default: the flexible Polak-Ribiere beta with the reduced-precision V-cycle)")
+    ap.add_argument("--cg-flexible", action="store_true",
+                    help="flexible (Polak-Ribiere) beta in the CG instead of Fletcher-Reeves")
     ap.add_argument("--no-fused-restriction", action="store_true",
                     help="restrict the level-0 residual with two kernels instead of the pre-multiplied operator")
     ap.add_argument("--no-collapse", action="store_true",
@@ -340,7 +340,7 @@ def main():
                 edge_currents_every_step=True, smoother=args.smoother, extrapolate=args.extrapolate,
                 nu_fine=args.nu_fine, fused_restriction=not args.no_fused_restriction, cheb_lo=args.cheb_lo,
                 precond_fp32=(False if args.precond_fp64 else 1 if args.precond_fp32 else True), collapse=not args.no_collapse, tail_cycles=args.tail_cycles,
-                guess_window=args.guess_window, flexible_cg=not args.cg_fr)
+                guess_window=args.guess_window, flexible_cg=args.cg_flexible)
 
     def run_workload(name, want_cpu_state):
         """Set up `name`, pre-roll + warm up, time K steps.  Returns a dict of measurements (rank 0

@@ -123,12 +123,14 @@ typedef struct {
                              are stored in IEEE binary16 -- same PCG iteration count; falls back
                              to 1 when an entry exceeds binary16's range.  0: everything fp64.  */
     int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..8 (0 = 6)   */
-    int32_t flexible_cg;  /* 1 (default): beta = z_{k+1}.(r_{k+1} - r_k) / z_k.r_k (Polak-Ribiere, the
-                             "flexible" CG), which tolerates a preconditioner that is not exactly
-                             symmetric -- the V-cycle's operators are rounded to fp32 / binary16
-                             one by one.  0: beta = z_{k+1}.r_{k+1} / z_k.r_k (Fletcher-Reeves).
-                             Single-GPU recurrence only; the one-reduction CG of the decomposed
-                             run keeps the Fletcher-Reeves beta with fp32-stored operators      */
+    int32_t flexible_cg;  /* 1: beta = z_{k+1}.(r_{k+1} - r_k) / z_k.r_k (Polak-Ribiere, the "flexible" CG), which
+                             tolerates a preconditioner that is not exactly symmetric -- the V-cycle's
+                             operators are rounded to fp32 / binary16 one by one.  0 (default): beta =
+                             z_{k+1}.r_{k+1} / z_k.r_k (Fletcher-Reeves).  Measured (round 3): same
+                             iteration counts on the benchmark meshes (8.97 per step at 1M sites with
+                             either), 32 / 33 against 30 / 33 on a 600 : 1 graded mesh, and the extra
+                             dot product costs 1.5 us per iteration -- hence off by default.
+                             Single-GPU recurrence only                                             */
 } tdgl_poisson_options;
 
 /* ------------------------------------------------------------------ lifetime */

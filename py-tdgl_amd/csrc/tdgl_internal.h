@@ -300,7 +300,7 @@ struct tdgl_ctx {
     // dense tail launch (latency bound, HBM mostly idle) -- pending until some launch has taken it
     bool xsplit_pending = false;
     tdgl::XrArgs xsplit{};
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6, 1};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6, 0};
     // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
     // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
     // step's status block
