@@ -20,6 +20,48 @@ def _free_port():
 
 
 # ---------------------------------------------------------------- single-process checks
+def _cut_statistics(mesh, part, world):
+    """(cut edges, smallest / largest piece, connected components per piece)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+
+    e, n = mesh.edge_mesh.edges, len(mesh.sites)
+    cut = int((part[e[:, 0]] != part[e[:, 1]]).sum())
+    counts = np.bincount(part, minlength=world)
+    comps = []
+    for r in range(world):
+        idx = np.flatnonzero(part == r)
+        loc = np.full(n, -1)
+        loc[idx] = np.arange(len(idx))
+        k = (part[e[:, 0]] == r) & (part[e[:, 1]] == r)
+        g = sp.coo_matrix((np.ones(k.sum()), (loc[e[k, 0]], loc[e[k, 1]])), shape=(len(idx), len(idx)))
+        comps.append(int(connected_components(g, directed=False)[0]))
+    return cut, int(counts.min()), int(counts.max()), comps
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_coordinate_bisection_on_a_device_with_holes(world):
+    """Recursive coordinate bisection is geometric, so a non-convex device with holes (the reference's
+    own test device, fixture mesh_polygon: box + strip, two holes) is where it could go wrong: pieces
+    falling apart, cuts through the narrow parts much longer than a graph partitioner's.  Measured
+    against the square film, in the scale-free form cut / sqrt(n * world): every piece stays connected,
+    the pieces are balanced to one site, and the cut is no longer than 1.5 x the square film's figure."""
+    from conftest import load_golden
+    from helpers import mesh_from_golden
+    from tdgl_amd.partition import rcb_partition
+
+    device = mesh_from_golden(load_golden("mesh_polygon"))
+    square = synthetic_mesh(80, 80)
+    figures = {}
+    for name, mesh in (("device", device), ("square", square)):
+        part = rcb_partition(mesh.sites, world)
+        cut, lo, hi, comps = _cut_statistics(mesh, part, world)
+        assert hi - lo <= 1 and comps == [1] * world, (name, lo, hi, comps)
+        figures[name] = cut / np.sqrt(len(mesh.sites) * world)
+    assert figures["device"] <= 1.5 * figures["square"], figures
+
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_partition_is_balanced_and_halo_plan_is_consistent(world):
     from tdgl_amd.partition import build_local_problem, rcb_partition
