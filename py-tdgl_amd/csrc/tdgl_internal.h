@@ -145,7 +145,6 @@ struct XrArgs {
     double *scal, *x, *r, *part_rr_out;
     int64_t n;
     int npart;  // entries of every partial array in use (tdgl_ctx::npart)
-    int mode;   // 0: x and r; 1: r only (+ bookkeeping, alpha -> scal[S_ALPHA]); 2: x only, alpha from scal[S_ALPHA]
 };
 
 constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels.inc: GK)
@@ -296,10 +295,6 @@ struct tdgl_ctx {
     // took it along
     bool xr_active = false, xr_carried = false;
     tdgl::XrArgs xr{};
-    // split CG update (poisson.inc): r -= alpha q right after A p; x += alpha p rides in the next iteration's
-    // dense tail launch (latency bound, HBM mostly idle) -- pending until some launch has taken it
-    bool xsplit_pending = false;
-    tdgl::XrArgs xsplit{};
     tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6, 0};
     // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
     // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
