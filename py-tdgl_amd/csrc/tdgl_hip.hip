@@ -505,7 +505,7 @@ static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
                        ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
                        guess_start ? ctx->part_gdot.p : (const double *)nullptr, (double)ctx->n_global,
-                       ctx->popt.rtol * ctx->popt.rtol, rr_part, ctx->npart);
+                       ctx->popt.rtol * ctx->popt.rtol, rr_part);
     ctx->psi_status_pending = false;
 }
 
