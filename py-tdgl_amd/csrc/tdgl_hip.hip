@@ -1137,7 +1137,7 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
     DevBuf<unsigned> bar_cnt;
     DevBuf<int> bar_err;
     DevBuf<double2> big;
-    if (kernel >= 16 && kernel <= 20) HIP_TRY(ctx, big.alloc((size_t)1 << 26));  // 1 GiB
+    if (kernel >= 16 && kernel <= 21) HIP_TRY(ctx, big.alloc((size_t)1 << 26));  // 1 GiB
     HIP_TRY(ctx, bar_cnt.alloc(1));
     HIP_TRY(ctx, bar_err.alloc(32));
     HIP_TRY(ctx, tmp_c.alloc(ctx->n_pad));
@@ -1211,6 +1211,10 @@ extern "C" int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, dou
             case 20:  // ... one pass, no loop: a workgroup per 256 x 2 entries
                 hipLaunchKernelGGL(k_stream_read<2>, dim3((unsigned)(big.n / (BLOCK * 2))), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n,
                                    (const double2 *)big.p, tmp_r.p);
+                break;
+            case 21:  // one workgroup reading 2 MiB from L2, 50 times
+                hipLaunchKernelGGL(k_one_cu_read, dim3(1), dim3(1024), 0, ctx->stream, 50, (int64_t)(1 << 17), (const double2 *)big.p,
+                                   tmp_r.p);
                 break;
             case 17:  // copy 512 MiB -> 512 MiB
                 hipLaunchKernelGGL(k_stream_copy<4>, dim3(256 * 8), dim3(BLOCK), 0, ctx->stream, (int64_t)big.n / 2,

@@ -34,3 +34,5 @@ ms = ctx.time_kernel(16, 20); print(f"  read-only: {gib / (ms * 1e-3) / 1e12:.2f
 ms = ctx.time_kernel(17, 20); print(f"  copy (512 MiB -> 512 MiB): {gib / (ms * 1e-3) / 1e12:.2f} TB/s moved")
 for k, name in ((18, "read-only, 8 loads per lane in flight"), (19, "read-only, 16 workgroups per CU"), (20, "read-only, one workgroup per 512 entries")):
     ms = ctx.time_kernel(k, 20); print(f"  {name}: {gib / (ms * 1e-3) / 1e12:.2f} TB/s")
+ms = ctx.time_kernel(21, 10)
+print(f"one workgroup (1024 threads, one CU) reading an L2-resident 2 MiB buffer: {50 * 2.0**21 / (ms * 1e-3) / 1e9:.0f} GB/s")
