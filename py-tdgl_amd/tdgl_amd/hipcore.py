@@ -137,14 +137,10 @@ class TDGLContext:
 
     # -- Poisson set-up -------------------------------------------------------------------
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
-                      edge_currents_every_step=True, max_coarse=None, smoother="chebyshev",
+                      edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
                       cheb_lo=0.1, extrapolate=3, nu_fine=1) -> Hierarchy:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
-        operators.py:305-308) + upload.  ``max_coarse``: rows at which coarsening stops and a dense
-        pseudo-inverse takes over; default 600, and 64 for meshes small enough for the
-        single-workgroup solver (`k_pcg_small`, up to 16,384 sites), where one CU applies it."""
-        if max_coarse is None:
-            max_coarse = 64 if (self.n <= 16384 and self.n_owned == self.n) else 600
+        operators.py:305-308) + upload."""
         k = self._keep
         with _Stopwatch(self.setup_times, "amg_host"):
             A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)

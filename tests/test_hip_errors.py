@@ -202,32 +202,3 @@ def test_run_restarts_from_recorded_controller_state():
     assert max_abs(remove_mean(got["mu"]), remove_mean(end["mu"])) < 1e-8 * max(1.0, np.abs(end["mu"]).max())
     with pytest.raises(ValueError, match="tentative_dt must be positive"):
         t.ctx.set_controller_state(0.0, [])
-
-
-def test_single_workgroup_solver_matches_the_launch_per_kernel_path(monkeypatch):
-    """Meshes up to 16,384 sites solve for mu inside ONE workgroup (`k_pcg_small`: all PCG iterations and
-    the V-cycle behind s_barriers instead of kernel boundaries).  Same equation, same tolerance: the
-    solution, the trajectory and the iteration counts must agree with the launch-per-kernel path on the
-    same hierarchy (TDGL_NO_SMALL_PCG switches back)."""
-    from oracle.fv_operators import laplacian_matrix
-
-    runs = {}
-    for name in ("one_workgroup", "launches"):
-        if name == "launches":
-            monkeypatch.setenv("TDGL_NO_SMALL_PCG", "1")
-        mesh, s = _small_transport_solver()
-        ctx = s.ctx
-        assert len(ctx.hierarchy.sizes) >= 2 and ctx.hierarchy.sizes[-1] <= 64
-        rhs = np.random.default_rng(1).normal(size=ctx.n)
-        rhs -= (rhs * mesh.areas).sum() / mesh.areas.sum()
-        mu, iters, relres = ctx.poisson_solve(rhs)
-        lap, _ = laplacian_matrix(mesh)
-        assert relres <= 1e-10 and max_abs(lap @ mu, rhs) < 1e-7 * np.abs(rhs).max()
-        res = ctx.run(300)
-        runs[name] = (mu, iters, res, ctx.get_state())
-    a, b = runs["one_workgroup"], runs["launches"]
-    assert max_abs(a[0], b[0]) < 1e-8 * np.abs(b[0]).max() and abs(a[1] - b[1]) <= 2
-    assert max_abs(a[2]["dt"], b[2]["dt"]) <= 1e-8 * b[2]["dt"].max()
-    assert abs(a[2]["pcg_iters"].mean() - b[2]["pcg_iters"].mean()) < 1.5
-    assert max_abs(np.abs(a[3]["psi"]) ** 2, np.abs(b[3]["psi"]) ** 2) < 1e-7
-    assert max_abs(remove_mean(a[3]["mu"]), remove_mean(b[3]["mu"])) < 1e-7 * max(1.0, np.abs(b[3]["mu"]).max())
