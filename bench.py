@@ -103,14 +103,16 @@ def traffic_of(table, prefix):
 
 
 def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, terms=(), currents=None, keep_at=0,
-                 probes=None):
+                 extra_states=()):
     """Time the oracle (NumPy/SciPy port of the reference step: SuperLU + sparse matvecs) on this host,
     starting from the GPU run's post-warm-up state -- fields, loop state and the adaptive-dt
     controller's history, so that it takes the very steps the timed GPU window took.  Setup (operator
     build, LU factorisation) is excluded, like the GPU path's setup.
 
-    Returns ``(baseline, run)``: the ``cpu_baseline`` object of the JSON line, and the oracle's dt
-    sequence plus its fields after ``keep_at`` steps (the checker's side of ``parity_vs_oracle``)."""
+    Returns ``(baseline, run, extra_runs)``: the ``cpu_baseline`` object of the JSON line, the oracle's dt
+    sequence plus its fields after ``keep_at`` steps (the checker's side of ``parity_vs_oracle``), and the
+    same for every further recorded state in ``extra_states`` (``(state, K)`` pairs; untimed, same
+    factorisation)."""
     from oracle import OracleSolver
 
     o = SimpleNamespace(skip_time=0.0, terminal_psi=0.0, **opt_kw)
@@ -118,27 +120,31 @@ def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, term
     solver = OracleSolver(mesh, A, 1.0, 5.79, 10.0, o, terminals=terms,
                           current_func=None if currents is None else (lambda t: currents))
     setup_s = time.perf_counter() - t0
-    solver.tentative_dt = state["tentative_dt"]
-    solver.d_psi_sq_vals = [float(v) for v in state["history"]]  # solver.py:318: the list persists
-    psi, mu = state["psi"].copy(), state["mu"].copy()
-    t, dt, step0 = state["time"], state["dt"], int(state["step"])
-    dts, kept = [], None
-    n_done, n_timed, t_start = 0, 0, None
-    while n_done < max_steps:
-        new_dt, psi, mu, js, jn = solver.update({"step": step0 + n_done, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
-        dts.append(float(new_dt))
-        n_done += 1
-        if n_done == keep_at:
-            kept = dict(psi=psi.copy(), mu=mu.copy(), supercurrent=js.copy(), normal_current=jn.copy())
-        dt = new_dt  # runner.py:431-433
-        t += dt
-        if t_start is None:
-            t_start = time.perf_counter()  # the first step is untimed (first-touch effects)
-        else:
-            n_timed += 1
-            if time.perf_counter() - t_start > target_seconds and n_done >= keep_at:
-                break
-    elapsed = time.perf_counter() - t_start
+    def follow(state, keep_at, max_steps, target_seconds):
+        solver.tentative_dt = state["tentative_dt"]
+        solver.d_psi_sq_vals = [float(v) for v in state["history"]]  # solver.py:318: the list persists
+        psi, mu = state["psi"].copy(), state["mu"].copy()
+        t, dt, step0 = state["time"], state["dt"], int(state["step"])
+        dts, kept = [], None
+        n_done, n_timed, t_start = 0, 0, None
+        while n_done < max_steps:
+            new_dt, psi, mu, js, jn = solver.update({"step": step0 + n_done, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
+            dts.append(float(new_dt))
+            n_done += 1
+            if n_done == keep_at:
+                kept = dict(psi=psi.copy(), mu=mu.copy(), supercurrent=js.copy(), normal_current=jn.copy())
+            dt = new_dt  # runner.py:431-433
+            t += dt
+            if t_start is None:
+                t_start = time.perf_counter()  # the first step is untimed (first-touch effects)
+            else:
+                n_timed += 1
+                if time.perf_counter() - t_start > target_seconds and n_done >= keep_at:
+                    break
+        return dict(dt=np.array(dts), kept=kept, keep_at=keep_at), n_timed, time.perf_counter() - t_start
+
+    run, n_timed, elapsed = follow(state, keep_at, max_steps, target_seconds)
+    extra_runs = [follow(st, k, k, 0.0)[0] for st, k in extra_states]
     base = dict(
         value=n_timed / elapsed,
         unit="steps/s",
@@ -148,7 +154,7 @@ def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, term
                f"same dt controller history; oracle = NumPy/SciPy restatement (scipy SuperLU solve + sparse matvecs, "
                f"single thread); setup excluded ({setup_s:.0f} s, mostly LU factorisation); host has {os.cpu_count()} logical cores",
     )
-    return base, dict(dt=np.array(dts), kept=kept, keep_at=keep_at)
+    return base, run, extra_runs
 
 
 PARITY_TOL = 1e-8
@@ -424,7 +430,7 @@ def main():
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
-            end_state=end_state, work=work, setup=setup,
+            end_state=end_state, work=work, setup=setup, vortex_start=None, vortex_end=None, vortex_dt=None,
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats()), overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
@@ -454,6 +460,12 @@ def main():
                 found = total
             if found is not None and total >= found + args.vortex_settle:
                 break
+        want_par = r.start_state is not None and not args.no_parity
+        if want_par:  # recorded start of the window: the oracle follows it from here too
+            st = ctx.get_state(supercurrent=False, normal_current=False)
+            ls0, cs0 = ctx.loop_state(), ctx.controller_state()
+            r.vortex_start = dict(psi=st["psi"], mu=st["mu"], step=ls0["step"], time=ls0["time"], dt=ls0["dt"],
+                                  tentative_dt=cs0["tentative_dt"], history=cs0["history"])
         ctx.step_stats(reset=True)
         ctx.synchronize()
         t_begin = time.perf_counter()
@@ -461,6 +473,9 @@ def main():
         ctx.synchronize()
         elapsed = time.perf_counter() - t_begin
         work, ls = ctx.step_stats(), ctx.loop_state()
+        if want_par:
+            r.vortex_dt = res["dt"].copy()
+            r.vortex_end = ctx.get_state() if args.steps <= PARITY_STEPS else None
         dts.append(res["dt"])
         its.append(res["pcg_iters"])
         r.trace["dt"] += np.concatenate(dts).tolist()
@@ -647,29 +662,38 @@ def main():
         wl = r.wl
         want_parity = not args.no_parity
         K = min(args.steps, PARITY_STEPS) if want_parity else 0
-        base, oracle_run = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
-                                        terms=wl.terms, currents=wl.currents, keep_at=K)
+        extra = [(r.vortex_start, K)] if (want_parity and r.vortex_start is not None) else []
+        base, oracle_run, extra_runs = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
+                                                    terms=wl.terms, currents=wl.currents, keep_at=K, extra_states=extra)
         out["cpu_baseline"] = base
         out["speedup_vs_cpu_baseline"] = round(out["value"] / base["value"], 1)
         base["value"] = round(base["value"], 4)
+
+        def hip_side(st0, timed_dt, end_state):
+            """dt sequence and fields of the HIP path after K steps from the recorded state st0."""
+            if end_state is not None:  # the timed window itself was K steps long
+                return timed_dt, end_state, "the timed steps themselves"
+            # the timed window is longer than the oracle can follow: its first K steps are taken again
+            # from the recorded start state (fields, loop state, dt controller history)
+            r.ctx.set_state(st0["psi"], st0["mu"])
+            r.ctx.set_loop_state(st0["step"], st0["time"], st0["dt"])
+            r.ctx.set_controller_state(st0["tentative_dt"], st0["history"])
+            replay = r.ctx.run(K)
+            redo = float(np.max(np.abs(replay["dt"] - timed_dt[:K])) / np.max(replay["dt"]))
+            return replay["dt"], r.ctx.get_state(), (
+                f"first {K} of the {args.steps} timed steps, taken again from the recorded start state "
+                f"(dt sequence of the replay vs the timed run: {redo:.1e} relative)")
+
         if want_parity:
-            if r.end_state is not None:  # the timed window itself was K steps long
-                hip_dt, hip_state, source = r.res["dt"], r.end_state, "the timed steps themselves"
-            else:
-                # the timed window is longer than the oracle can follow: its first K steps are taken again
-                # from the recorded start state (fields, loop state, dt controller history)
-                st0 = r.start_state
-                r.ctx.set_state(st0["psi"], st0["mu"])
-                r.ctx.set_loop_state(st0["step"], st0["time"], st0["dt"])
-                r.ctx.set_controller_state(st0["tentative_dt"], st0["history"])
-                replay = r.ctx.run(K)
-                hip_dt, hip_state = replay["dt"], r.ctx.get_state()
-                redo = float(np.max(np.abs(replay["dt"] - r.res["dt"][:K])) / np.max(replay["dt"]))
-                source = (f"first {K} of the {args.steps} timed steps, taken again from the recorded start state "
-                          f"(dt sequence of the replay vs the timed run: {redo:.1e} relative)")
+            hip_dt, hip_state, source = hip_side(r.start_state, r.res["dt"], r.end_state)
             out["parity_vs_oracle"] = parity_block(hip_dt, hip_state, oracle_run, source)
             parity_failed = not out["parity_vs_oracle"]["ok"]
             log(f"parity vs oracle: {out['parity_vs_oracle']}")
+            if extra_runs:  # ... and in the vortex state
+                v_dt, v_state, v_source = hip_side(r.vortex_start, r.vortex_dt, r.vortex_end)
+                out["vortex_window"]["parity_vs_oracle"] = parity_block(v_dt, v_state, extra_runs[0], v_source)
+                parity_failed = parity_failed or not out["vortex_window"]["parity_vs_oracle"]["ok"]
+                log(f"parity vs oracle in the vortex window: {out['vortex_window']['parity_vs_oracle']}")
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
