@@ -443,7 +443,16 @@ int tdgl_vcycle(tdgl_ctx *ctx, const double *r, double *z);
  * 7 = induced vector potential (screening; n_edges * n_sites pairs, ~12 fp64 flops each),
  * 8 / 9 = two trivial dependent kernels across two streams (event record + wait each way) / in one
  * stream: their difference is the price of the two cross-stream dependencies an overlapped halo
- * exchange pays. */
+ * exchange pays;
+ * 10-15 = 100 device-wide barriers inside ONE launch (avg_ms is per launch): cooperative-groups
+ * grid.sync() with 32 / 256 workgroups (10 / 11; the kernel syncs twice per round, i.e. 200), a
+ * monotonic counter with agent-scope fences with 32 / 256 workgroups (12 / 13), with the 32 workgroups
+ * of one XCD (14), the same with L2-local fences (15: NOT coherent, counts its stale reads);
+ * tdgl_last_error then reports stale reads and the XCC_ID of workgroups 0-15;
+ * 16-20 = HBM-cold streaming over a 1 GiB buffer: grid-stride read-only sum (16; 18 with 8 loads per lane
+ * in flight, 19 with 16 workgroups per CU, 20 one workgroup per 512 entries), copy 512 MiB -> 512 MiB (17);
+ * 21 = one workgroup of 1024 threads reading an L2-resident 2 MiB buffer 50 times (bytes one CU gets).
+ * tools/bench_barrier.py prints all of them. */
 int tdgl_time_kernel(tdgl_ctx *ctx, int32_t kernel, int32_t reps, double *avg_ms);
 /* Enable/disable HIP-event timing of the fused psi-Laplacian kernel inside tdgl_run, and
  * read back the accumulated launches / milliseconds. */
