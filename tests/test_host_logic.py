@@ -916,3 +916,37 @@ def float_or(text):
         return float(text)
     except (TypeError, ValueError):
         return text
+
+
+def test_bench_parity_checker_on_the_cpu():
+    """`bench.py`'s checker side without a GPU: `cpu_baseline` follows a recorded state (fields, loop state,
+    dt controller history) with the oracle, keeps the fields after K steps -- also for a second recorded
+    state (the vortex window's) -- and `parity_block` turns two runs into the `parity_vs_oracle` object:
+    zero deviation and `ok` for the oracle against itself, `ok = False` beyond 1e-8."""
+    import bench
+    from oracle import OracleSolver
+    from types import SimpleNamespace
+
+    mesh = synthetic_mesh(12)
+    A = uniform_field_A(mesh, 0.3)
+    o = SimpleNamespace(skip_time=0.0, terminal_psi=0.0, **bench.OPT_KW)
+    solver = OracleSolver(mesh, A, 1.0, 5.79, 10.0, o)
+    psi, mu, t, dt = solver.psi_init.copy(), solver.mu_init.copy(), 0.0, o.dt_init
+    for i in range(15):  # a recorded point past the controller's window
+        dt, psi, mu, js, jn = solver.update({"step": i, "time": t, "dt": dt}, None, dt, psi=psi, mu=mu)
+        t += dt
+    state = dict(psi=psi, mu=mu, step=15, time=t, dt=dt, tentative_dt=solver.tentative_dt, history=list(solver.d_psi_sq_vals))
+    want_dt, p2, m2, t2, d2 = [], psi.copy(), mu.copy(), t, dt
+    for i in range(4):  # what the uninterrupted run does next
+        d2, p2, m2, js, jn = solver.update({"step": 15 + i, "time": t2, "dt": d2}, None, d2, psi=p2, mu=m2)
+        want_dt.append(d2)
+        t2 += d2
+    base, run, extra = bench.cpu_baseline(mesh, A, state, bench.OPT_KW, target_seconds=0.0, max_steps=6, keep_at=4,
+                                          extra_states=[(state, 4)])
+    assert base["kind"] == "port" and base["cores"] == 1 and base["value"] > 0
+    assert np.allclose(run["dt"][:4], want_dt, rtol=1e-13) and np.array_equal(extra[0]["dt"], run["dt"][:4])
+    hip_like = dict(psi=p2, mu=m2 + 0.7, supercurrent=js, normal_current=jn)  # (a constant in mu is gauge)
+    blk = bench.parity_block(np.array(want_dt), hip_like, run, "test")
+    assert blk["ok"] and blk["steps"] == 4 and max(blk[k] for k in ("dt", "abs_sq_psi", "mu_zero_mean", "J_s", "J_n")) < 1e-12
+    off = dict(hip_like, supercurrent=js + 1e-6)
+    assert not bench.parity_block(np.array(want_dt), off, run, "test")["ok"]
