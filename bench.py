@@ -299,6 +299,8 @@ def main():
                          "(min |psi|^2 < 0.05; vortices / phase slips) and time a second window there; auto = single GPU")
     ap.add_argument("--vortex-max-steps", type=int, default=5000, help="steps the search for that state may take")
     ap.add_argument("--vortex-settle", type=int, default=500, help="steps between reaching that state and the window")
+    ap.add_argument("--late-steps", type=int, default=6000,
+                    help="steps after the vortex window before a third timed window in the long-time regime (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the domain-decomposition driver (RCCL communicator) even on one GPU")
@@ -430,7 +432,7 @@ def main():
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
-            end_state=end_state, work=work, setup=setup, vortex_start=None, vortex_end=None, vortex_dt=None,
+            end_state=end_state, work=work, setup=setup, windows={},
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats()), overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
@@ -460,12 +462,24 @@ def main():
                 found = total
             if found is not None and total >= found + args.vortex_settle:
                 break
+        r.trace["dt"] += np.concatenate(dts).tolist()
+        r.trace["pcg_iters"] += np.concatenate(its).tolist()
+        r.trace["vortex_search"] = search
+        out_w = timed_window(r, free, "vortex")
+        out_w.update(state_reached=found is not None, steps_before_window=args.preroll + args.warmup + args.steps + total)
+        return out_w
+
+    def timed_window(r, free, label):
+        """Time --steps steps from wherever the run stands; records the window's start state (and, for short
+        windows, its end state) so that the oracle can follow the same steps (`windows[label]`)."""
+        ctx = r.ctx
         want_par = r.start_state is not None and not args.no_parity
+        rec = dict(start=None, dt=None, end=None)
         if want_par:  # recorded start of the window: the oracle follows it from here too
             st = ctx.get_state(supercurrent=False, normal_current=False)
             ls0, cs0 = ctx.loop_state(), ctx.controller_state()
-            r.vortex_start = dict(psi=st["psi"], mu=st["mu"], step=ls0["step"], time=ls0["time"], dt=ls0["dt"],
-                                  tentative_dt=cs0["tentative_dt"], history=cs0["history"])
+            rec["start"] = dict(psi=st["psi"], mu=st["mu"], step=ls0["step"], time=ls0["time"], dt=ls0["dt"],
+                                tentative_dt=cs0["tentative_dt"], history=cs0["history"])
         ctx.step_stats(reset=True)
         ctx.synchronize()
         t_begin = time.perf_counter()
@@ -474,29 +488,51 @@ def main():
         elapsed = time.perf_counter() - t_begin
         work, ls = ctx.step_stats(), ctx.loop_state()
         if want_par:
-            r.vortex_dt = res["dt"].copy()
-            r.vortex_end = ctx.get_state() if args.steps <= PARITY_STEPS else None
-        dts.append(res["dt"])
-        its.append(res["pcg_iters"])
-        r.trace["dt"] += np.concatenate(dts).tolist()
-        r.trace["pcg_iters"] += np.concatenate(its).tolist()
-        r.trace["vortex_search"] = search
+            rec["dt"] = res["dt"].copy()
+            rec["end"] = ctx.get_state() if args.steps <= PARITY_STEPS else None
+        r.windows[label] = rec
+        r.trace["dt"] += res["dt"].tolist()
+        r.trace["pcg_iters"] += res["pcg_iters"].tolist()
+        a2 = np.abs(ctx.get_state(mu=False, supercurrent=False, normal_current=False)["psi"][free]) ** 2
         return dict(
             value=round(args.steps / elapsed, 3), unit="steps/s", ms_per_step=round(1e3 * elapsed / args.steps, 4), steps=args.steps,
-            state_reached=found is not None, steps_before_window=args.preroll + args.warmup + args.steps + total,
-            simulated_time=round(ls["time"], 3), min_abs_sq_psi=search[-1]["min_abs_sq_psi"],
-            sites_below_0p1=search[-1]["sites_below_0p1"],
+            simulated_time=round(ls["time"], 3), min_abs_sq_psi=float(a2.min()), sites_below_0p1=int((a2 < 0.1).sum()),
             pcg=dict(mean_iterations=round(float(res["pcg_iters"].mean()), 2), max_iterations=int(res["pcg_iters"].max())),
             retries=int(work["psi_retries"]), host_syncs_per_step=round(work["host_syncs"] / max(work["steps"], 1), 2),
             dt=dict(mean=float(res["dt"].mean()), min=float(res["dt"].min()), max=float(res["dt"].max())),
             guess=ctx.guess_stats(),
         )
 
-    vortex = None
+    def late_window(r):
+        """... and the long-time regime: --late-steps further steps (the adaptive step reaches dt_max, the psi
+        update starts to fail there and is repeated with dt / 4, the right-hand side of the mu equation
+        moves more from step to step), then a third timed window."""
+        ctx, wl = r.ctx, r.wl
+        free = np.ones(r.n, dtype=bool)
+        for t in wl.terms:
+            free[np.asarray(t["site_indices"])] = False
+        ctx.step_stats(reset=True)
+        done, chunks = 0, []
+        while done < args.late_steps:
+            res = ctx.run(min(2000, args.late_steps - done))
+            done += len(res["dt"])
+            r.trace["dt"] += res["dt"].tolist()
+            r.trace["pcg_iters"] += res["pcg_iters"].tolist()
+            chunks.append(dict(steps=done, dt_last=float(res["dt"][-1]), dt_max=float(res["dt"].max()),
+                               pcg_mean=round(float(res["pcg_iters"].mean()), 2)))
+        retries_before = int(ctx.step_stats()["psi_retries"])
+        out_w = timed_window(r, free, "late")
+        out_w.update(steps_after_vortex_window=done, psi_retries_on_the_way=retries_before, on_the_way=chunks)
+        return out_w
+
+    vortex = late = None
     want_vortex = args.vortex_window == "on" or (args.vortex_window == "auto" and not use_dd)
     if want_vortex and rank == 0 and not use_dd:
         vortex = vortex_window(main_run)
         log(f"vortex window: {vortex}")
+        if args.late_steps > 0:
+            late = late_window(main_run)
+            log(f"late window: {late}")
     if args.trace_iterations and rank == 0:
         with open(args.trace_iterations, "w") as f:
             json.dump(dict(workload=args.workload, preroll=args.preroll, warmup=args.warmup, steps=args.steps,
@@ -617,6 +653,8 @@ def main():
     )
     if vortex is not None:
         out["vortex_window"] = vortex
+    if late is not None:
+        out["late_window"] = late
     if rank == 0 and "comm_per_step" in main_line:
         out["comm_per_step"] = main_line["comm_per_step"]
     # BASELINE config 5 next to the headline workload (decomposed runs).  The headline measurement is
@@ -662,7 +700,8 @@ def main():
         wl = r.wl
         want_parity = not args.no_parity
         K = min(args.steps, PARITY_STEPS) if want_parity else 0
-        extra = [(r.vortex_start, K)] if (want_parity and r.vortex_start is not None) else []
+        labels = [lb for lb in ("vortex", "late") if want_parity and r.windows.get(lb, {}).get("start") is not None]
+        extra = [(r.windows[lb]["start"], K) for lb in labels]
         base, oracle_run, extra_runs = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
                                                     terms=wl.terms, currents=wl.currents, keep_at=K, extra_states=extra)
         out["cpu_baseline"] = base
@@ -689,11 +728,14 @@ def main():
             out["parity_vs_oracle"] = parity_block(hip_dt, hip_state, oracle_run, source)
             parity_failed = not out["parity_vs_oracle"]["ok"]
             log(f"parity vs oracle: {out['parity_vs_oracle']}")
-            if extra_runs:  # ... and in the vortex state
-                v_dt, v_state, v_source = hip_side(r.vortex_start, r.vortex_dt, r.vortex_end)
-                out["vortex_window"]["parity_vs_oracle"] = parity_block(v_dt, v_state, extra_runs[0], v_source)
-                parity_failed = parity_failed or not out["vortex_window"]["parity_vs_oracle"]["ok"]
-                log(f"parity vs oracle in the vortex window: {out['vortex_window']['parity_vs_oracle']}")
+            # ... and inside the later windows (reported; only the headline window decides the exit status: a
+            # psi update that fails by a hair on one side and passes on the other would be a property of
+            # the trajectory, not of the kernels)
+            for lb, xr in zip(labels, extra_runs):
+                w = r.windows[lb]
+                v_dt, v_state, v_source = hip_side(w["start"], w["dt"], w["end"])
+                out[lb + "_window"]["parity_vs_oracle"] = parity_block(v_dt, v_state, xr, v_source)
+                log(f"parity vs oracle in the {lb} window: {out[lb + '_window']['parity_vs_oracle']}")
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
