@@ -202,6 +202,18 @@ int tdgl_poisson_set_collapsed_up(tdgl_ctx *ctx, int32_t level, const int32_t *w
                                   const double *w_data, const int32_t *v_indptr, const int32_t *v_indices,
                                   const double *v_data);
 int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *tail);
+/* Direct mu solve for small meshes.  The reference factorises L_mu once (operators.py:305-308) and
+ * back-substitutes every step (solver.py:516); on the GPU a triangular solve is a chain of dependent
+ * launches, so the factorisation's counterpart here is the explicit pseudo-inverse G = pinv(A) of
+ * A = -diag(a) L_mu (symmetric, null space = constants), dense [n, n] row major, in the site order of
+ * the hierarchy's level 0, and every solve is ONE matrix-vector product mu = G b (k_dense_solve):
+ * n^2 doubles streamed per step -- cheaper than the ~60 dependent launches of the AMG-PCG path up to
+ * ~10^4 sites (268 MB / 55 us at 5.8k sites).  The zero-mean solution comes out by construction
+ * (G annihilates constants on both sides).  While set, tdgl_run / tdgl_poisson_solve use it instead of
+ * the PCG iteration (iteration counts read 0; tdgl_poisson_solve still reports the true relative
+ * residual).  G == NULL switches back to AMG-PCG.  Single GPU only (TDGL_ERR_ARG otherwise);
+ * a hierarchy must have been set (its level-0 matrix measures the residual). */
+int tdgl_poisson_set_dense_inverse(tdgl_ctx *ctx, const double *G, int64_t n);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);

@@ -266,6 +266,12 @@ struct tdgl_ctx {
     int64_t f32_fallbacks = 0;            // solves that had to be finished with the fp64 operators
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
+    // direct solve for small meshes (tdgl_poisson_set_dense_inverse): mu = G b, G = pinv(A) dense
+    // [n, dense_ld] row major; replaces the PCG iteration while set (single GPU only)
+    tdgl::DevBuf<double> denseG;
+    int64_t dense_ld = 0;
+    bool spec_currents = false;           // step driver: queue the edge currents right behind the dense solve,
+    bool spec_currents_done = false;      // before the host has seen the step's status (run.inc)
     // collapsed coarse chain (tdgl_poisson_set_collapsed_tail): everything from level `tail_level`
     // down as explicit operators, built for the smoother settings (tail_nu, tail_smoother, tail_cheb_lo)
     int tail_level = -1;                  // -1: off

@@ -417,6 +417,42 @@ def exact_pinv(A) -> np.ndarray:
     return np.linalg.inv(M + J) - J
 
 
+def dense_pseudo_inverse(A: sp.spmatrix, check_rtol: float = 1e-11, seed: int = 0):
+    """``pinv(A)`` of the level-0 Poisson matrix as a dense symmetric array, for the direct solve
+    of small meshes (`tdgl_poisson_set_dense_inverse`): the counterpart of the reference's LU
+    factorisation (operators.py:305-308) in a form whose application is one dense matrix-vector
+    product.  ``A`` is symmetric positive semi-definite with the constants as its null space, so
+    ``A + (s/n) 1 1^T`` is positive definite (s = mean diagonal: the added eigenvalue sits inside the
+    spectrum), its Cholesky inverse is ``pinv(A) + 1 1^T / (s n)``, and the rank-one term is removed
+    again.  Returns ``None`` when the factorisation fails (a mesh of several disconnected pieces has
+    a larger null space) or when ``||A G b - b|| > check_rtol ||b||`` for a random zero-mean ``b``
+    (ill conditioned: stay with the iterative solver, which controls its residual)."""
+    from scipy.linalg import lapack
+
+    n = A.shape[0]
+    s = float(A.diagonal().mean())
+    if not (s > 0.0) or not np.isfinite(s):
+        return None
+    M = A.toarray(order="F")
+    M += s / n
+    c, info = lapack.dpotrf(M, lower=1, overwrite_a=1)
+    if info != 0:
+        return None
+    G, info = lapack.dpotri(c, lower=1, overwrite_c=1)
+    if info != 0:
+        return None
+    # dpotri fills the lower triangle only: mirror it (the result is exactly symmetric)
+    il = np.tril_indices(n, -1)
+    G.T[il] = G[il]
+    G -= 1.0 / (s * n)
+    G = np.ascontiguousarray(G)
+    b = np.random.default_rng(seed).standard_normal(n)
+    b -= b.mean()
+    if not np.linalg.norm(A @ (G @ b) - b) <= check_rtol * np.linalg.norm(b):
+        return None
+    return G
+
+
 def _drop_small_symmetric(W: sp.csr_matrix, tol: float) -> sp.csr_matrix:
     """``W`` without the off-diagonal entries below ``tol * sqrt(|w_ii w_jj|)`` (symmetric criterion)."""
     C = W.tocoo()

@@ -116,6 +116,7 @@ class TDGLContext:
         with _Stopwatch(self.setup_times, "upload"):
             _lib.check(self._lib.tdgl_create(C.byref(self._ctx), C.byref(desc), int(device_id)))
         self.hierarchy = None
+        self.dense_direct = False  # mu solve = one dense matrix-vector product (set_dense_inverse)
 
     # -- lifetime ---------------------------------------------------------------------
     def close(self):
@@ -136,11 +137,17 @@ class TDGLContext:
         self._chk(self._lib.tdgl_synchronize(self._ctx))
 
     # -- Poisson set-up -------------------------------------------------------------------
+    # meshes up to this many sites get the direct solve (one dense matrix-vector product per step,
+    # `tdgl_poisson_set_dense_inverse`) unless build_poisson is told otherwise
+    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "12288"))
+
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
-                      cheb_lo=0.1, extrapolate=3, nu_fine=1) -> Hierarchy:
+                      cheb_lo=0.1, extrapolate=3, nu_fine=1, dense_max_sites=None) -> Hierarchy:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
-        operators.py:305-308) + upload."""
+        operators.py:305-308) + upload.  Single-GPU meshes of at most ``dense_max_sites`` sites
+        (default `DENSE_MAX_SITES`; 0 = never) additionally get the explicit pseudo-inverse of the
+        Poisson matrix and solve with it (`set_dense_inverse`)."""
         k = self._keep
         with _Stopwatch(self.setup_times, "amg_host"):
             A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
@@ -149,7 +156,29 @@ class TDGLContext:
         self.set_hierarchy(h)
         self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step,
                                  smoother, cheb_lo, extrapolate, nu_fine)
+        limit = self.DENSE_MAX_SITES if dense_max_sites is None else int(dense_max_sites)
+        if self.n_owned == self.n and 2 <= self.n <= limit:
+            from .amg import dense_pseudo_inverse
+
+            with _Stopwatch(self.setup_times, "dense_inverse_host"):
+                G = dense_pseudo_inverse(A)
+            if G is not None:
+                self.set_dense_inverse(G)
         return h
+
+    def set_dense_inverse(self, G):
+        """Solve the mu equation as ``mu = G b`` from now on (``G`` = pinv of the level-0 Poisson
+        matrix, dense [n, n], internal site order); ``None`` returns to AMG-PCG."""
+        if G is None:
+            self._chk(self._lib.tdgl_poisson_set_dense_inverse(self._ctx, None, 0))
+            self.dense_direct = False
+            return
+        G = f64(G)
+        if G.shape != (self.n, self.n):
+            raise ValueError(f"dense inverse must be [{self.n}, {self.n}], got {G.shape}")
+        with _Stopwatch(self.setup_times, "upload"):
+            self._chk(self._lib.tdgl_poisson_set_dense_inverse(self._ctx, p_f64(G), self.n))
+        self.dense_direct = True
 
     # -- one process per GPU -------------------------------------------------------------
     def set_halo_plan(self, lp):

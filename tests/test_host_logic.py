@@ -950,3 +950,29 @@ def test_bench_parity_checker_on_the_cpu():
     assert blk["ok"] and blk["steps"] == 4 and max(blk[k] for k in ("dt", "abs_sq_psi", "mu_zero_mean", "J_s", "J_n")) < 1e-12
     off = dict(hip_like, supercurrent=js + 1e-6)
     assert not bench.parity_block(np.array(want_dt), off, run, "test")["ok"]
+
+
+def test_dense_pseudo_inverse_of_the_poisson_matrix():
+    """Set-up of the direct solve for small meshes (amg.dense_pseudo_inverse): G = pinv(A) is symmetric,
+    annihilates the constants on both sides, solves A x = b on their complement to round-off, and is
+    refused for a mesh in two pieces (two-dimensional null space)."""
+    import scipy.sparse as sp
+
+    from tdgl_amd.amg import dense_pseudo_inverse, exact_pinv
+    from tdgl_amd.hipcore import poisson_matrix
+
+    mesh = synthetic_mesh(24)
+    em = mesh.edge_mesh
+    n = len(mesh.sites)
+    A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, n)
+    G = dense_pseudo_inverse(A)
+    assert G is not None and G.shape == (n, n) and G.flags["C_CONTIGUOUS"]
+    assert np.array_equal(G, G.T)
+    assert np.abs(G.sum(axis=0)).max() < 1e-12 * np.abs(G).max() * n
+    assert np.abs(G - exact_pinv(A)).max() < 1e-10 * np.abs(G).max()
+    b = np.random.default_rng(3).standard_normal(n)
+    x = G @ b
+    assert abs(x.mean()) < 1e-13 * np.abs(x).max()
+    assert np.linalg.norm(A @ x - (b - b.mean())) < 1e-12 * np.linalg.norm(b)
+    two = sp.block_diag([A, A]).tocsr()
+    assert dense_pseudo_inverse(two) is None
