@@ -44,6 +44,12 @@ METRIC = "tdgl_steps_per_sec"
 WORKLOADS = {
     # name: (side in xi, description)           site counts follow SURVEY.md §8(d)
     "5k": (70.0, "square film 70 xi, 5,791 sites"),
+    # sizes around the switch between the direct (dense) and the iterative mu solve
+    "2k": (42.0, "square film 42 xi, ~2.1k sites"),
+    "9k": (88.0, "square film 88 xi, ~9k sites"),
+    "12k": (101.0, "square film 101 xi, ~12k sites"),
+    "16k": (117.0, "square film 117 xi, ~16k sites"),
+    "23k": (140.0, "square film 140 xi, ~23k sites"),
     "60k": (226.0, "square film 226 xi, 59,377 sites"),
     "250k": (465.0, "square film 465 xi, 250,510 sites"),
     "1M": (930.0, "square film 930 xi, 1,000,431 sites"),
@@ -383,6 +389,10 @@ def main():
         st = dict(getattr(ctx, "setup_times", {}))
         setup = dict(mesh=round(wl.mesh_s, 2) if wl is not None else None, reorder=round(st.get("reorder", 0.0), 2),
                      amg_host=round(st.get("amg_host", 0.0), 2), upload=round(st.get("upload", 0.0), 2), total=round(total_s, 2))
+        if getattr(ctx, "dense_direct", False):  # small meshes: explicit pseudo-inverse, built on the device (or the host's LAPACK)
+            setup["dense_inverse"] = round(st.get("dense_inverse_device", 0.0) + st.get("dense_inverse_host", 0.0), 2)
+            setup["dense_inverse_on"] = "device" if "dense_inverse_device" in st else "host"
+        setup["mu_solver"] = "direct (dense pseudo-inverse)" if getattr(ctx, "dense_direct", False) else "amg_pcg"
         log(f"rank {rank}: {name} set-up {total_s:.1f} s {setup}; AMG levels {h.sizes}, "
             f"operator complexity {h.operator_complexity:.2f}")
         ctx.begin_stage()

@@ -214,6 +214,14 @@ int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *ta
  * residual).  G == NULL switches back to AMG-PCG.  Single GPU only (TDGL_ERR_ARG otherwise);
  * a hierarchy must have been set (its level-0 matrix measures the residual). */
 int tdgl_poisson_set_dense_inverse(tdgl_ctx *ctx, const double *G, int64_t n);
+/* The same, with G computed on the device from the hierarchy's level-0 matrix (the set-up counterpart of
+ * operators.py:305-308 without the host): M = A + (s/n) 1 1^T assembled dense, inverted in place by
+ * rocSOLVER's Cholesky routines (dpotrf + dpotri, loaded with dlopen at the first call), packed into the
+ * symmetric tile layout with 1 1^T / (s n) removed.  *seconds (may be NULL) = wall time of the call.
+ * TDGL_ERR_NOT_READY when rocBLAS / rocSOLVER cannot be loaded (use tdgl_poisson_set_dense_inverse with
+ * a host-computed G then), TDGL_ERR_ARG when the factorisation breaks down (a mesh in several pieces
+ * has a larger null space: stay with AMG-PCG). */
+int tdgl_poisson_build_dense_inverse(tdgl_ctx *ctx, double *seconds);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);

@@ -544,6 +544,7 @@ static inline int64_t now_ns() {
 
 #include "comm.inc"
 #include "poisson.inc"
+#include "dense.inc"
 #include "screening.inc"
 #include "run.inc"
 

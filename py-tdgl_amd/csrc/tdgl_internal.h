@@ -269,7 +269,9 @@ struct tdgl_ctx {
     // direct solve for small meshes (tdgl_poisson_set_dense_inverse): mu = G b, G = pinv(A) dense
     // [n, dense_ld] row major; replaces the PCG iteration while set (single GPU only)
     tdgl::DevBuf<double> denseG;
-    int64_t dense_ld = 0;
+    int64_t dense_ld = 0;                 // > 0: in use
+    int dense_tiles = 0;                  // > 0: symmetric packed storage, tiles per side (k_dense_sym_tiles)
+    tdgl::DevBuf<double> dense_part;      // its per-tile contributions [dense_tiles][dense_tiles * DT]
     bool spec_currents = false;           // step driver: queue the edge currents right behind the dense solve,
     bool spec_currents_done = false;      // before the host has seen the step's status (run.inc)
     // collapsed coarse chain (tdgl_poisson_set_collapsed_tail): everything from level `tail_level`

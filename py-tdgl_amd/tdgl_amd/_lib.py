@@ -163,6 +163,7 @@ SIGNATURES = {
     "tdgl_poisson_set_collapsed_up": (C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p]),
     "tdgl_poisson_set_collapsed_tail": (C.c_int, [_CTX, C.POINTER(CollapsedTail)]),
     "tdgl_poisson_set_dense_inverse": (C.c_int, [_CTX, c_f64p, C.c_int64]),
+    "tdgl_poisson_build_dense_inverse": (C.c_int, [_CTX, c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
     "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),

@@ -139,7 +139,7 @@ class TDGLContext:
     # -- Poisson set-up -------------------------------------------------------------------
     # meshes up to this many sites get the direct solve (one dense matrix-vector product per step,
     # `tdgl_poisson_set_dense_inverse`) unless build_poisson is told otherwise
-    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "12288"))
+    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "16384"))
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
@@ -158,13 +158,45 @@ class TDGLContext:
                                  smoother, cheb_lo, extrapolate, nu_fine)
         limit = self.DENSE_MAX_SITES if dense_max_sites is None else int(dense_max_sites)
         if self.n_owned == self.n and 2 <= self.n <= limit:
+            self.build_dense_inverse(A)
+        return h
+
+    def build_dense_inverse(self, A=None, check_rtol=1e-11) -> bool:
+        """Switch the mu solve to the explicit pseudo-inverse (`tdgl_poisson_set_dense_inverse`): built on
+        the device (`tdgl_poisson_build_dense_inverse`); on the host with LAPACK when rocSOLVER cannot be
+        loaded.  The result is checked on a random right-hand side (``||b - A G b|| <= check_rtol ||b||``,
+        the residual the library reports for a one-off solve); a matrix that fails, or whose
+        factorisation breaks down (a mesh in several pieces), stays with AMG-PCG.  Returns whether the
+        direct solve is on."""
+        import os
+
+        ok = False
+        if not os.environ.get("TDGL_DENSE_HOST"):
+            sec = C.c_double(0.0)
+            status = self._lib.tdgl_poisson_build_dense_inverse(self._ctx, C.byref(sec))
+            if status == _lib.TDGL_OK:
+                self.setup_times["dense_inverse_device"] = sec.value
+                ok = True
+            elif status != _lib.TDGL_ERR_NOT_READY:
+                return False  # (not positive definite on the complement of the constants)
+        if not ok:
             from .amg import dense_pseudo_inverse
 
+            if A is None:
+                k = self._keep
+                A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
             with _Stopwatch(self.setup_times, "dense_inverse_host"):
-                G = dense_pseudo_inverse(A)
-            if G is not None:
-                self.set_dense_inverse(G)
-        return h
+                G = dense_pseudo_inverse(A, check_rtol=check_rtol)
+            if G is None:
+                return False
+            self.set_dense_inverse(G)
+        self.dense_direct = True
+        b = np.random.default_rng(0).standard_normal(self.n)
+        _, _, relres = self.poisson_solve(b)
+        if not relres <= check_rtol:
+            self.set_dense_inverse(None)
+            return False
+        return True
 
     def set_dense_inverse(self, G):
         """Solve the mu equation as ``mu = G b`` from now on (``G`` = pinv of the level-0 Poisson
