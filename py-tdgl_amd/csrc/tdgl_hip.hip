@@ -495,6 +495,16 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
     ctx->psi_status_pending = true;
 }
 
+// ... with the edge currents of the step just accepted in the same launch (k_psi_update_with_currents)
+static void launch_psi_update_with_currents(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
+                                            double dt, double2 *psi_new) {
+    hipLaunchKernelGGL(k_psi_update_with_currents, dim3(ctx->psi_blocks + grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->psi_blocks, ctx->n_own, psi, mu, ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new,
+                       ctx->psi_dmax_part.p, ctx->psi_fail_part.p, ctx->m, ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p,
+                       ctx->e_U.p, ctx->js.p, ctx->jn.p);
+    ctx->psi_status_pending = true;
+}
+
 // reduce the outcome of the last psi update into d_status (together with the PCG scalars);
 // guess_start: first synchronisation of a solve with the projection guess (sums its partial arrays,
 // sets S_BB / S_TOL2, resets the iteration counters); rr_part: residual partials to sum into S_RR

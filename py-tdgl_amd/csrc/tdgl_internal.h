@@ -272,6 +272,7 @@ struct tdgl_ctx {
     int64_t dense_ld = 0;                 // > 0: in use
     int dense_tiles = 0;                  // > 0: symmetric packed storage, tiles per side (k_dense_sym_tiles)
     tdgl::DevBuf<double> dense_part;      // its per-tile contributions [dense_tiles][dense_tiles * DT]
+    bool currents_deferred = false;       // J of the last accepted step ride in the next step's psi-update launch
     bool spec_currents = false;           // step driver: queue the edge currents right behind the dense solve,
     bool spec_currents_done = false;      // before the host has seen the step's status (run.inc)
     // collapsed coarse chain (tdgl_poisson_set_collapsed_tail): everything from level `tail_level`

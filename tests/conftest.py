@@ -26,24 +26,32 @@ def golden():
     return load_golden
 
 
-@pytest.fixture(autouse=True)
-def _iterative_mu_solve_unless_asked(request, monkeypatch):
+_PRODUCT_DENSE_MAX_SITES = None
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _iterative_mu_solve_unless_asked():
     """The product solves the mu equation of meshes up to `TDGLContext.DENSE_MAX_SITES` sites with one
     dense matrix-vector product (`tdgl_poisson_set_dense_inverse`).  Most fixtures are that small, so
-    the suites keep the AMG-PCG path under test by default; tests that request the ``direct_solve``
-    fixture (tests/test_hip_direct.py re-runs the trajectory suite that way) get the product default."""
-    if "direct_solve" in request.fixturenames:
-        return
+    the suites keep the AMG-PCG path under test by default (session-wide, so that module-scoped contexts
+    see it too); tests that request the ``direct_solve`` fixture (tests/test_hip_direct.py re-runs the
+    trajectory suite that way) get the product default back."""
+    global _PRODUCT_DENSE_MAX_SITES
     try:
         from tdgl_amd.hipcore import TDGLContext
     except Exception:  # (library not built: the tests that need it fail on their own)
+        yield
         return
-    monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", 0)
+    _PRODUCT_DENSE_MAX_SITES = TDGLContext.DENSE_MAX_SITES
+    TDGLContext.DENSE_MAX_SITES = 0
+    yield
+    TDGLContext.DENSE_MAX_SITES = _PRODUCT_DENSE_MAX_SITES
 
 
 @pytest.fixture
-def direct_solve():
+def direct_solve(monkeypatch):
     from tdgl_amd.hipcore import TDGLContext
 
-    assert TDGLContext.DENSE_MAX_SITES >= 8192  # the product default covers the reference's documented mesh sizes
-    return TDGLContext.DENSE_MAX_SITES
+    assert _PRODUCT_DENSE_MAX_SITES >= 8192  # the product default covers the reference's documented mesh sizes
+    monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", _PRODUCT_DENSE_MAX_SITES)
+    return _PRODUCT_DENSE_MAX_SITES
