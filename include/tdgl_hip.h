@@ -222,6 +222,41 @@ int tdgl_poisson_set_dense_inverse(tdgl_ctx *ctx, const double *G, int64_t n);
  * a host-computed G then), TDGL_ERR_ARG when the factorisation breaks down (a mesh in several pieces
  * has a larger null space: stay with AMG-PCG). */
 int tdgl_poisson_build_dense_inverse(tdgl_ctx *ctx, double *seconds);
+
+/* Substructured direct mu solve for mid-size meshes (between the dense inverse above and AMG-PCG): one
+ * level of nested dissection with every factor explicit, so that the reference's back-substitution
+ * (solver.py:516 with the LU of operators.py:305-308) becomes four launches of dense row products.
+ * The context's site order must be "interiors of the P parts, part by part, then the separator"
+ * (tdgl_mesh_desc.site_perm; host layer: tdgl_amd/substructure.py).  With G_p = A_pp^-1,
+ * E_p = G_p A_pS and the Schur complement S_c = A_SS - sum_p A_Sp E_p:
+ *     w = [ G_p b_p | b_S - sum_p E_p^T b_p | (G_p 1)^T b_p ]       k_sub_down (rows of dense segments)
+ *     x_S = pinv(S_c) w_S                                             k_dense_sym_tiles + k_dense_sym_finish
+ *     x_p = w_p - E_p x_S,  minus the mean (sum x = sum_p w_{n+p} + u^T x_S)   k_sub_up
+ * The way down is given as rows of segments over one value pool: output row r =
+ * sum_{k in [seg_ptr[r], seg_ptr[r+1])} vals[seg_val[k] .. + seg_len[k]) . b[seg_x[k] .. + seg_len[k]),
+ * rows [0, n_interior) = G rows, [n_interior, n) = separator rows (b_S as a one-entry segment with value 1,
+ * minus the E^T rows), [n, n + n_parts) = (G_p 1)^T.  `schur` is the SINGULAR Schur complement; the
+ * library forms its pseudo-inverse on the device (the blocked sweep of tdgl_poisson_build_dense_inverse).
+ * s == NULL switches back to AMG-PCG.  Single GPU only; a hierarchy must have been set. */
+typedef struct {
+    int64_t n_interior, n_sep;
+    int32_t n_parts;
+    const int32_t *part_ptr;  /* [n_parts + 1] interior ranges                                  */
+    const int32_t *seg_ptr;   /* [n_interior + n_sep + n_parts + 1]                             */
+    const int64_t *seg_val;   /* [n_seg] offset into vals                                       */
+    const int32_t *seg_x;     /* [n_seg] first entry of b                                       */
+    const int32_t *seg_len;   /* [n_seg]                                                        */
+    const double *vals;
+    int64_t n_vals;
+    const int32_t *sep_ptr;   /* [n_parts + 1] into sep_idx                                     */
+    const int32_t *sep_idx;   /* separator-local indices of the sites part p touches            */
+    const int64_t *e_off;     /* [n_parts] offset of E_p (n_p x s_p, row major) in e_vals       */
+    const double *e_vals;
+    int64_t n_e;
+    const double *u;          /* [n_sep]  -sum_p E_p^T 1                                        */
+    const double *schur;      /* [n_sep, n_sep] row major                                       */
+} tdgl_substructure;
+int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, double *seconds);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);

@@ -272,6 +272,18 @@ struct tdgl_ctx {
     int64_t dense_ld = 0;                 // > 0: in use
     int dense_tiles = 0;                  // > 0: symmetric packed storage, tiles per side (k_dense_sym_tiles)
     tdgl::DevBuf<double> dense_part;      // its per-tile contributions [dense_tiles][dense_tiles * DT]
+    // substructured direct solve (tdgl_poisson_set_substructure): the Schur pseudo-inverse lives in
+    // denseG / dense_part / dense_tiles (dense_n = n_sep)
+    int64_t dense_n = 0;                  // order of the matrix in denseG (n, or n_sep)
+    int32_t sub_parts = 0;                // > 0: in use
+    int64_t sub_nI = 0, sub_nS = 0;
+    tdgl::DevBuf<int32_t> sub_part_ptr, sub_seg_ptr, sub_seg_x, sub_seg_len, sub_sep_ptr, sub_sep_idx, sub_row_part;
+    tdgl::DevBuf<int64_t> sub_seg_val, sub_e_off;
+    tdgl::DevBuf<double> sub_vals, sub_e, sub_u;
+    tdgl::DevBuf<double> sub_w;           // [n + parts] result of the way down
+    tdgl::DevBuf<double> sub_xs;          // [n_sep] separator solution before the mean is removed
+    tdgl::DevBuf<double> sub_upart;       // per-workgroup partials of u . x_S
+    int sub_nfin = 0;                     // workgroups of k_dense_sym_finish
     bool currents_deferred = false;       // J of the last accepted step ride in the next step's psi-update launch
     bool spec_currents = false;           // step driver: queue the edge currents right behind the dense solve,
     bool spec_currents_done = false;      // before the host has seen the step's status (run.inc)

@@ -129,6 +129,28 @@ class CollapsedTail(C.Structure):
     ]
 
 
+class Substructure(C.Structure):
+    _fields_ = [
+        ("n_interior", C.c_int64),
+        ("n_sep", C.c_int64),
+        ("n_parts", C.c_int32),
+        ("part_ptr", c_i32p),
+        ("seg_ptr", c_i32p),
+        ("seg_val", C.POINTER(C.c_int64)),
+        ("seg_x", c_i32p),
+        ("seg_len", c_i32p),
+        ("vals", c_f64p),
+        ("n_vals", C.c_int64),
+        ("sep_ptr", c_i32p),
+        ("sep_idx", c_i32p),
+        ("e_off", C.POINTER(C.c_int64)),
+        ("e_vals", c_f64p),
+        ("n_e", C.c_int64),
+        ("u", c_f64p),
+        ("schur", c_f64p),
+    ]
+
+
 class ScreeningOptions(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_int32),
@@ -164,6 +186,7 @@ SIGNATURES = {
     "tdgl_poisson_set_collapsed_tail": (C.c_int, [_CTX, C.POINTER(CollapsedTail)]),
     "tdgl_poisson_set_dense_inverse": (C.c_int, [_CTX, c_f64p, C.c_int64]),
     "tdgl_poisson_build_dense_inverse": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_poisson_set_substructure": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
     "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),

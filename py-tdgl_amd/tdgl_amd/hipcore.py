@@ -87,9 +87,19 @@ class TDGLContext:
         self.n_owned = int(n_owned) if n_owned else self.n
         if n_owned:
             reorder = None
+        self._sub_part_ptr = None
         if reorder == "rcm":
             with _Stopwatch(self.setup_times, "reorder"):
                 perm = rcm_permutation(em.edges, self.n)
+                if self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
+                    # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
+                    # then the separator" as the site order (substructure.py); inside a part the sites keep
+                    # their reverse Cuthill-McKee order
+                    from .substructure import substructure_order
+
+                    rank = np.empty(self.n, dtype=np.int64)
+                    rank[perm] = np.arange(self.n)
+                    perm, self._sub_part_ptr = substructure_order(np.asarray(mesh.sites), em.edges, self.SUB_BLOCK, rank_hint=rank)
         elif reorder is None or reorder == "none":
             perm = np.arange(self.n, dtype=np.int32)
         else:
@@ -116,7 +126,8 @@ class TDGLContext:
         with _Stopwatch(self.setup_times, "upload"):
             _lib.check(self._lib.tdgl_create(C.byref(self._ctx), C.byref(desc), int(device_id)))
         self.hierarchy = None
-        self.dense_direct = False  # mu solve = one dense matrix-vector product (set_dense_inverse)
+        self.dense_direct = False  # mu solve = a direct one (set_dense_inverse / build_substructure)
+        self.substructure = None
 
     # -- lifetime ---------------------------------------------------------------------
     def close(self):
@@ -140,6 +151,10 @@ class TDGLContext:
     # meshes up to this many sites get the direct solve (one dense matrix-vector product per step,
     # `tdgl_poisson_set_dense_inverse`) unless build_poisson is told otherwise
     DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "16384"))
+    # ... and up to this many the substructured direct solve (`tdgl_poisson_set_substructure`): parts of
+    # ~SUB_BLOCK sites with explicit inverses, a dense Schur complement on the separator
+    SUB_MAX_SITES = int(__import__("os").environ.get("TDGL_SUB_MAX_SITES", "150000"))
+    SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "448"))
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
@@ -157,9 +172,49 @@ class TDGLContext:
         self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step,
                                  smoother, cheb_lo, extrapolate, nu_fine)
         limit = self.DENSE_MAX_SITES if dense_max_sites is None else int(dense_max_sites)
-        if self.n_owned == self.n and 2 <= self.n <= limit:
+        if self.n_owned == self.n and self._sub_part_ptr is not None and dense_max_sites is None:
+            self.build_substructure(A)
+        elif self.n_owned == self.n and 2 <= self.n <= limit:
             self.build_dense_inverse(A)
         return h
+
+    def build_substructure(self, A=None, check_rtol=1e-11) -> bool:
+        """Switch the mu solve to the substructured direct solve (`tdgl_poisson_set_substructure`); the
+        context must have been created with the substructure site order (mid-size meshes are).  Checked on a
+        random right-hand side like `build_dense_inverse`; returns whether it is on."""
+        from .substructure import build_substructure, pack_for_device
+
+        if self._sub_part_ptr is None:
+            raise ValueError("this context's site order is not a substructure order")
+        if A is None:
+            k = self._keep
+            A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
+        with _Stopwatch(self.setup_times, "substructure_host"):
+            try:
+                sub = build_substructure(A, self._sub_part_ptr)
+            except (ValueError, np.linalg.LinAlgError):
+                return False
+            pk = pack_for_device(sub)
+        d = _lib.Substructure(
+            n_interior=pk["n_interior"], n_sep=pk["n_sep"], n_parts=pk["n_parts"], part_ptr=p_i32(pk["part_ptr"]),
+            seg_ptr=p_i32(pk["seg_ptr"]), seg_val=pk["seg_val"].ctypes.data_as(C.POINTER(C.c_int64)), seg_x=p_i32(pk["seg_x"]),
+            seg_len=p_i32(pk["seg_len"]), vals=p_f64(pk["vals"]), n_vals=len(pk["vals"]), sep_ptr=p_i32(pk["sep_ptr"]),
+            sep_idx=p_i32(pk["sep_idx"]), e_off=pk["e_off"].ctypes.data_as(C.POINTER(C.c_int64)), e_vals=p_f64(pk["e_vals"]),
+            n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=p_f64(pk["schur"]),
+        )
+        sec = C.c_double(0.0)
+        status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(d), C.byref(sec))
+        if status != _lib.TDGL_OK:
+            return False
+        self.setup_times["substructure_device"] = sec.value
+        self.substructure = dict(parts=sub.n_parts, separator=sub.n_sep, bytes_per_solve=sub.bytes_per_solve())
+        self.dense_direct = True
+        b = np.random.default_rng(0).standard_normal(self.n)
+        _, _, relres = self.poisson_solve(b)
+        if not relres <= check_rtol:
+            self.set_dense_inverse(None)
+            return False
+        return True
 
     def build_dense_inverse(self, A=None, check_rtol=1e-11) -> bool:
         """Switch the mu solve to the explicit pseudo-inverse (`tdgl_poisson_set_dense_inverse`): built on

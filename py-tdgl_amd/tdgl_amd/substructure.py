@@ -1,0 +1,225 @@
+"""Set-up of the substructured direct mu solve for mid-size meshes (`tdgl_poisson_set_substructure`).
+
+The reference factorises ``L_mu`` once with a sparse LU (operators.py:305-308) and back-substitutes
+every step (solver.py:516).  A triangular solve is a long chain of dependent launches on a GPU, an
+explicit inverse of the whole matrix (`tdgl_poisson_set_dense_inverse`) streams n^2 doubles per step and
+stops paying at ~16k sites.  In between sits one level of nested dissection with every factor made
+explicit, so that a solve is four launches of dense row products:
+
+* the sites are cut into P compact parts (recursive coordinate bisection) and a vertex separator S (the
+  sites of a part with a neighbour in a higher part); interiors first, part by part, then S -- this IS
+  the library's internal site order (`substructure_order` is passed as the context's permutation);
+* per part: ``G_p = A_pp^-1`` (dense, n_p ~ 450) and ``E_p = G_p A_pS`` (dense, n_p x s_p with s_p the
+  ~100 separator sites the part touches); the Schur complement ``S_c = A_SS - sum_p A_Sp E_p`` (dense,
+  singular like A: its null space is the constants);
+* a solve:  ``y_p = G_p b_p``,  ``r_S = b_S - sum_p E_p^T b_p``  (one launch: every output is a sum of
+  dense row segments),  ``x_S = pinv(S_c) r_S``  (the symmetric dense kernel pair of the small-mesh
+  solve),  ``x_p = y_p - E_p x_S``  and the removal of the mean, which is known before the last launch:
+  ``sum x = sum_p (G_p 1)^T b_p + u^T x_S`` with ``u = -sum_p E_p^T 1``.
+
+Bytes per solve at 59k sites with 128 parts: 220 MB of G, 2 x 36 MB of E, 117 MB of the Schur pseudo-
+inverse -- 0.4 GB, ~75 us, against nine PCG iterations of ~30 us.  The crossover with AMG-PCG is where the
+separator's dense inverse stops fitting the time budget (~150k sites).
+
+`solve_host` restates the device algorithm in NumPy (CPU tests; not used by the product path).
+"""
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import scipy.sparse as sp
+
+from .partition import rcb_partition
+
+
+def substructure_order(sites: np.ndarray, edges: np.ndarray, target_block: int = 448, rank_hint=None):
+    """Permutation ``perm`` (internal -> reference site) and ``part_ptr`` ([P + 1]: interior ranges of the
+    parts in internal numbering; the separator is ``[part_ptr[P], n)``).  ``rank_hint[i]`` orders the
+    sites inside a part (e.g. their reverse Cuthill-McKee rank: keeps the stencil's gathers local)."""
+    n = len(sites)
+    nparts = max(2, int(round(n / float(target_block))))
+    part = rcb_partition(np.asarray(sites, dtype=float), nparts)
+    i, j = edges[:, 0], edges[:, 1]
+    is_sep = np.zeros(n, dtype=bool)
+    # a vertex cover of the cut edges: the endpoint in the lower part
+    lo_i = part[i] < part[j]
+    lo_j = part[j] < part[i]
+    is_sep[i[lo_i]] = True
+    is_sep[j[lo_j]] = True
+    key = np.arange(n) if rank_hint is None else np.asarray(rank_hint)
+    group = np.where(is_sep, nparts, part)
+    perm = np.lexsort((key, group)).astype(np.int32)
+    counts = np.bincount(group, minlength=nparts + 1)
+    part_ptr = np.concatenate([[0], np.cumsum(counts[:nparts])]).astype(np.int32)
+    return perm, part_ptr
+
+
+@dataclass
+class Substructure:
+    n: int
+    part_ptr: np.ndarray          # [P + 1]
+    G: List[np.ndarray]           # per part [n_p, n_p]
+    E: List[np.ndarray]           # per part [n_p, s_p]
+    sep_idx: List[np.ndarray]     # per part: separator-local indices of the s_p separator sites it touches
+    schur: np.ndarray             # [n_S, n_S], symmetric, singular (null space: constants)
+    g: np.ndarray                 # [n_I]  G_p 1 per part, concatenated
+    u: np.ndarray                 # [n_S]  -sum_p E_p^T 1
+
+    @property
+    def n_parts(self):
+        return len(self.G)
+
+    @property
+    def n_interior(self):
+        return int(self.part_ptr[-1])
+
+    @property
+    def n_sep(self):
+        return self.n - self.n_interior
+
+    def bytes_per_solve(self):
+        sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
+        return sum(8 * g.size for g in self.G) + 2 * sum(8 * e.size for e in self.E) + sym(self.n_sep)
+
+
+def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray) -> Substructure:
+    """``A`` = the level-0 Poisson matrix in the internal order `substructure_order` produced."""
+    A = A.tocsr()
+    n = A.shape[0]
+    P = len(part_ptr) - 1
+    nI = int(part_ptr[-1])
+    nS = n - nI
+    if nS < 2:
+        raise ValueError("substructure: no separator (a single part?)")
+    ASS = A[nI:, nI:].toarray()
+    schur = ASS
+    G, E, sidx = [], [], []
+    g = np.empty(nI)
+    u = np.zeros(nS)
+    AIS = A[:nI, nI:].tocsr()
+    for p in range(P):
+        a, b = int(part_ptr[p]), int(part_ptr[p + 1])
+        App = A[a:b, a:b].toarray()
+        # (cross-part couplings between interiors do not exist: the separator covers every cut edge)
+        Gp = np.linalg.inv(App)
+        Gp = 0.5 * (Gp + Gp.T)
+        ApS = AIS[a:b]
+        cols = np.unique(ApS.indices)
+        Ep = Gp @ ApS[:, cols].toarray()
+        schur[np.ix_(cols, cols)] -= ApS[:, cols].toarray().T @ Ep
+        G.append(np.ascontiguousarray(Gp))
+        E.append(np.ascontiguousarray(Ep))
+        sidx.append(cols.astype(np.int32))
+        g[a:b] = Gp.sum(axis=1)
+        u[cols] -= Ep.sum(axis=0)
+    # interiors of different parts must not be coupled
+    off = A[:nI, :nI].tocoo()
+    pr = np.searchsorted(part_ptr, off.row, side="right")
+    pc = np.searchsorted(part_ptr, off.col, side="right")
+    if np.any(pr != pc):
+        raise ValueError("substructure: the separator does not cover every cut edge")
+    schur = 0.5 * (schur + schur.T)
+    return Substructure(n=n, part_ptr=np.asarray(part_ptr, dtype=np.int32), G=G, E=E, sep_idx=sidx, schur=schur, g=g, u=u)
+
+
+def schur_pinv(schur: np.ndarray) -> np.ndarray:
+    """pinv of the singular Schur complement (null space = constants), as `amg.dense_pseudo_inverse` does."""
+    m = schur.shape[0]
+    s = float(np.diag(schur).mean())
+    inv = np.linalg.inv(schur + s / m)
+    return 0.5 * (inv + inv.T) - 1.0 / (s * m)
+
+
+def solve_host(sub: Substructure, b: np.ndarray, spinv: np.ndarray = None) -> np.ndarray:
+    """The device algorithm in NumPy: the zero-mean solution of ``A x = b - mean(b)``."""
+    nI, P = sub.n_interior, sub.n_parts
+    if spinv is None:
+        spinv = schur_pinv(sub.schur)
+    y = np.empty(nI)
+    r = b[nI:].copy()
+    gd = np.empty(P)
+    for p in range(P):
+        a, e = int(sub.part_ptr[p]), int(sub.part_ptr[p + 1])
+        y[a:e] = sub.G[p] @ b[a:e]
+        r[sub.sep_idx[p]] -= sub.E[p].T @ b[a:e]
+        gd[p] = sub.g[a:e] @ b[a:e]
+    xs = spinv @ r
+    mean = (gd.sum() + sub.u @ xs) / sub.n
+    x = np.empty(sub.n)
+    for p in range(P):
+        a, e = int(sub.part_ptr[p]), int(sub.part_ptr[p + 1])
+        x[a:e] = y[a:e] - sub.E[p] @ xs[sub.sep_idx[p]] - mean
+    x[nI:] = xs - mean
+    return x
+
+
+def pack_for_device(sub: Substructure):
+    """Flat arrays of `tdgl_substructure` (include/tdgl_hip.h): the way down as rows of dense segments
+    over one value pool -- rows [0, n_I): ``G_p`` rows; rows [n_I, n): ``b_S`` itself (a segment of one
+    entry with value 1) minus the ``E_p^T`` rows of the parts that touch the site; rows [n, n + P):
+    ``(G_p 1)^T`` -- and the way up as the ``E_p`` blocks with their separator index lists."""
+    nI, nS, P, n = sub.n_interior, sub.n_sep, sub.n_parts, sub.n
+    pp = sub.part_ptr
+    sizes = np.diff(pp).astype(np.int64)
+    # value pool: [1.0 | G blocks | -E^T blocks | g]
+    g_off = 1 + np.concatenate([[0], np.cumsum(sizes * sizes)])
+    s_cnt = np.array([len(s) for s in sub.sep_idx], dtype=np.int64)
+    et_off = g_off[-1] + np.concatenate([[0], np.cumsum(sizes * s_cnt)])
+    gvec_off = et_off[-1]
+    vals = np.empty(gvec_off + nI)
+    vals[0] = 1.0
+    for p in range(P):
+        vals[g_off[p]:g_off[p + 1]] = sub.G[p].ravel()
+        vals[et_off[p]:et_off[p + 1]] = (-sub.E[p].T).ravel()
+    vals[gvec_off:] = sub.g
+    # segments
+    seg_val, seg_x, seg_len, seg_row = [], [], [], []
+    # interior rows
+    rows_I = np.arange(nI, dtype=np.int64)
+    part_of = np.searchsorted(pp, rows_I, side="right") - 1
+    seg_val.append(g_off[part_of] + (rows_I - pp[part_of]) * sizes[part_of])
+    seg_x.append(pp[part_of].astype(np.int64))
+    seg_len.append(sizes[part_of])
+    seg_row.append(rows_I)
+    # separator rows: identity + one segment per touching part
+    seg_val.append(np.zeros(nS, dtype=np.int64))
+    seg_x.append(nI + np.arange(nS, dtype=np.int64))
+    seg_len.append(np.ones(nS, dtype=np.int64))
+    seg_row.append(nI + np.arange(nS, dtype=np.int64))
+    for p in range(P):
+        k = len(sub.sep_idx[p])
+        seg_val.append(et_off[p] + np.arange(k, dtype=np.int64) * sizes[p])
+        seg_x.append(np.full(k, pp[p], dtype=np.int64))
+        seg_len.append(np.full(k, sizes[p], dtype=np.int64))
+        seg_row.append(nI + sub.sep_idx[p].astype(np.int64))
+    # g rows
+    seg_val.append(gvec_off + pp[:-1].astype(np.int64))
+    seg_x.append(pp[:-1].astype(np.int64))
+    seg_len.append(sizes)
+    seg_row.append(n + np.arange(P, dtype=np.int64))
+    seg_val, seg_x, seg_len, seg_row = (np.concatenate(a) for a in (seg_val, seg_x, seg_len, seg_row))
+    order = np.argsort(seg_row, kind="stable")
+    seg_val, seg_x, seg_len, seg_row = seg_val[order], seg_x[order], seg_len[order], seg_row[order]
+    seg_ptr = np.concatenate([[0], np.cumsum(np.bincount(seg_row, minlength=n + P))]).astype(np.int32)
+    e_off = np.concatenate([[0], np.cumsum(sizes * s_cnt)]).astype(np.int64)
+    e_vals = np.concatenate([e.ravel() for e in sub.E]) if P else np.zeros(0)
+    sep_ptr = np.concatenate([[0], np.cumsum(s_cnt)]).astype(np.int32)
+    sep_idx = np.concatenate(sub.sep_idx).astype(np.int32)
+    return dict(
+        n_interior=nI, n_sep=nS, n_parts=P, part_ptr=pp.astype(np.int32),
+        seg_ptr=seg_ptr, seg_val=seg_val.astype(np.int64), seg_x=seg_x.astype(np.int32), seg_len=seg_len.astype(np.int32),
+        vals=np.ascontiguousarray(vals), sep_ptr=sep_ptr, sep_idx=sep_idx, e_off=e_off[:-1].copy(),
+        e_vals=np.ascontiguousarray(e_vals), u=np.ascontiguousarray(sub.u), schur=np.ascontiguousarray(sub.schur),
+    )
+
+
+def down_host(pk, b):
+    """`k_sub_down` restated on the packed arrays (tests: the packing itself)."""
+    nrows = len(pk["seg_ptr"]) - 1
+    out = np.zeros(nrows)
+    for r in range(nrows):
+        for k in range(pk["seg_ptr"][r], pk["seg_ptr"][r + 1]):
+            v0, x0, ln = int(pk["seg_val"][k]), int(pk["seg_x"][k]), int(pk["seg_len"][k])
+            out[r] += pk["vals"][v0:v0 + ln] @ b[x0:x0 + ln]
+    return out

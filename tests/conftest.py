@@ -27,6 +27,7 @@ def golden():
 
 
 _PRODUCT_DENSE_MAX_SITES = None
+_PRODUCT_SUB_MAX_SITES = None
 
 
 @pytest.fixture(autouse=True, scope="session")
@@ -36,16 +37,16 @@ def _iterative_mu_solve_unless_asked():
     the suites keep the AMG-PCG path under test by default (session-wide, so that module-scoped contexts
     see it too); tests that request the ``direct_solve`` fixture (tests/test_hip_direct.py re-runs the
     trajectory suite that way) get the product default back."""
-    global _PRODUCT_DENSE_MAX_SITES
+    global _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES
     try:
         from tdgl_amd.hipcore import TDGLContext
     except Exception:  # (library not built: the tests that need it fail on their own)
         yield
         return
-    _PRODUCT_DENSE_MAX_SITES = TDGLContext.DENSE_MAX_SITES
-    TDGLContext.DENSE_MAX_SITES = 0
+    _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES = TDGLContext.DENSE_MAX_SITES, TDGLContext.SUB_MAX_SITES
+    TDGLContext.DENSE_MAX_SITES = TDGLContext.SUB_MAX_SITES = 0
     yield
-    TDGLContext.DENSE_MAX_SITES = _PRODUCT_DENSE_MAX_SITES
+    TDGLContext.DENSE_MAX_SITES, TDGLContext.SUB_MAX_SITES = _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES
 
 
 @pytest.fixture
@@ -54,4 +55,17 @@ def direct_solve(monkeypatch):
 
     assert _PRODUCT_DENSE_MAX_SITES >= 8192  # the product default covers the reference's documented mesh sizes
     monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", _PRODUCT_DENSE_MAX_SITES)
+    monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", _PRODUCT_SUB_MAX_SITES)
     return _PRODUCT_DENSE_MAX_SITES
+
+
+@pytest.fixture
+def substructured_solve(monkeypatch):
+    """Every mesh from 200 sites up takes the substructured direct mu solve (parts of ~150 sites), which the
+    product uses between `DENSE_MAX_SITES` and `SUB_MAX_SITES`."""
+    from tdgl_amd.hipcore import TDGLContext
+
+    monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", 199)
+    monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", 10 ** 9)
+    monkeypatch.setattr(TDGLContext, "SUB_BLOCK", 150)
+    return 150

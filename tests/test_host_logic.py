@@ -976,3 +976,41 @@ def test_dense_pseudo_inverse_of_the_poisson_matrix():
     assert np.linalg.norm(A @ x - (b - b.mean())) < 1e-12 * np.linalg.norm(b)
     two = sp.block_diag([A, A]).tocsr()
     assert dense_pseudo_inverse(two) is None
+
+
+def test_substructured_solve_on_the_host():
+    """Set-up of the substructured direct solve (tdgl_amd/substructure.py): the order (interiors part by part,
+    then a separator that covers every cut edge), the block formulas (solve_host = the device algorithm) against
+    the dense pseudo-inverse, and the packed segment form the library consumes."""
+    from tdgl_amd.amg import exact_pinv
+    from tdgl_amd.hipcore import poisson_matrix, rcm_permutation
+    from tdgl_amd.substructure import build_substructure, down_host, pack_for_device, solve_host, substructure_order
+
+    mesh = synthetic_mesh(30)
+    em = mesh.edge_mesh
+    n = len(mesh.sites)
+    rcm = rcm_permutation(em.edges, n)
+    rank = np.empty(n, dtype=np.int64)
+    rank[rcm] = np.arange(n)
+    perm, pp = substructure_order(mesh.sites, em.edges, 120, rank_hint=rank)
+    assert sorted(perm.tolist()) == list(range(n)) and pp[0] == 0 and len(pp) - 1 >= 8 and pp[-1] < n
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[perm] = np.arange(n)
+    A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, n, iperm)
+    sub = build_substructure(A, pp)  # (raises when interiors of two parts are coupled)
+    assert sub.n_interior + sub.n_sep == n and sub.n_sep < 0.35 * n
+    assert np.abs(sub.schur.sum(axis=1)).max() < 1e-12 * np.abs(sub.schur).max()  # singular like A
+    b = np.random.default_rng(2).standard_normal(n)
+    b -= b.mean()
+    x = solve_host(sub, b)
+    want = exact_pinv(A) @ b
+    assert np.abs(x - want).max() < 1e-11 * np.abs(want).max() and abs(x.mean()) < 1e-14
+    pk = pack_for_device(sub)
+    w = down_host(pk, b)
+    nI, P = sub.n_interior, sub.n_parts
+    y = np.concatenate([sub.G[p] @ b[pp[p]:pp[p + 1]] for p in range(P)])
+    r = b[nI:].copy()
+    for p in range(P):
+        r[sub.sep_idx[p]] -= sub.E[p].T @ b[pp[p]:pp[p + 1]]
+    gd = np.array([sub.g[pp[p]:pp[p + 1]] @ b[pp[p]:pp[p + 1]] for p in range(P)])
+    assert np.abs(w - np.concatenate([y, r, gd])).max() < 1e-12 * np.abs(w).max()
