@@ -389,10 +389,18 @@ def main():
         st = dict(getattr(ctx, "setup_times", {}))
         setup = dict(mesh=round(wl.mesh_s, 2) if wl is not None else None, reorder=round(st.get("reorder", 0.0), 2),
                      amg_host=round(st.get("amg_host", 0.0), 2), upload=round(st.get("upload", 0.0), 2), total=round(total_s, 2))
-        if getattr(ctx, "dense_direct", False):  # small meshes: explicit pseudo-inverse, built on the device (or the host's LAPACK)
+        sub = getattr(ctx, "substructure", None)
+        if sub:  # mid-size meshes: substructured direct solve, factors formed on the device
+            setup["substructure"] = dict(host=round(st.get("substructure_host", 0.0), 2), device=round(st.get("substructure_device", 0.0), 2),
+                                         parts=sub["parts"], separator=sub["separator"], built_on=sub["built_on"],
+                                         mb_per_solve=round(sub["bytes_per_solve"] / 1e6, 1))
+            setup["mu_solver"] = "direct (substructured: dense interior blocks + dense Schur complement)"
+        elif getattr(ctx, "dense_direct", False):  # small meshes: explicit pseudo-inverse, built on the device (or the host's LAPACK)
             setup["dense_inverse"] = round(st.get("dense_inverse_device", 0.0) + st.get("dense_inverse_host", 0.0), 2)
             setup["dense_inverse_on"] = "device" if "dense_inverse_device" in st else "host"
-        setup["mu_solver"] = "direct (dense pseudo-inverse)" if getattr(ctx, "dense_direct", False) else "amg_pcg"
+            setup["mu_solver"] = "direct (dense pseudo-inverse)"
+        else:
+            setup["mu_solver"] = "amg_pcg"
         log(f"rank {rank}: {name} set-up {total_s:.1f} s {setup}; AMG levels {h.sizes}, "
             f"operator complexity {h.operator_complexity:.2f}")
         ctx.begin_stage()
@@ -640,10 +648,11 @@ def main():
         data="synthetic",
         config=dict(
             workload=f"{desc}, " + ("" if strip else f"uniform field b=B/Bc2={B_FIELD}, ") + f"adaptive dt (dt_init 1e-4, dt_max 0.1), "
-                     f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
-                     + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32"
-                        + ("" if args.precond_fp32 else " (level 0: binary16)") + ", all arithmetic and the CG in fp64")
-                     + f"), J_s/J_n formed every step; steady state: {args.preroll} pre-roll + {args.warmup} warm-up steps "
+                     + (f"mu solve: {r.setup['mu_solver']}" if r.setup.get("mu_solver", "amg_pcg") != "amg_pcg" else
+                        f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
+                        + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32"
+                           + ("" if args.precond_fp32 else " (level 0: binary16)") + ", all arithmetic and the CG in fp64") + ")")
+                     + f", J_s/J_n formed every step; steady state: {args.preroll} pre-roll + {args.warmup} warm-up steps "
                        f"untimed, then {args.steps} timed steps at {main_line['pcg']['mean_iterations']} PCG iterations per step",
             sites=r.n, edges=r.m, amg_levels=r.sizes, preroll=args.preroll,
             parallelism="single" if world == 1 else

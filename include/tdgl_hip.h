@@ -257,6 +257,40 @@ typedef struct {
     const double *schur;      /* [n_sep, n_sep] row major                                       */
 } tdgl_substructure;
 int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, double *seconds);
+/* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
+ * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
+ * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep
+ * (all parts at once, blockIdx.y = part); E_p = G_p A_pS and C_p = A_Sp E_p are sums of the two or
+ * three rows of G_p / E_p that the entries of A_pS select (ent_*: the entries grouped by (part,
+ * separator site) pair); the Schur complement is assembled row by row (A_SS as CSR minus the C_p rows of
+ * the pairs that touch the site, node_*: in ascending pair order -- deterministic) straight into the
+ * padded matrix the sweep inverts.  The value pool the way down reads is laid out as
+ * [1.0 | G_p at g_off[p], n_p x n_p | -E_p^T at et_off[p], s_p x n_p | G_p 1 at gvec_off + row]. */
+typedef struct {
+    int64_t n_interior, n_sep;
+    int32_t n_parts;
+    const int32_t *part_ptr;   /* [n_parts + 1]                                                         */
+    const int32_t *sep_ptr;    /* [n_parts + 1] pairs of each part                                      */
+    const int32_t *sep_idx;    /* [n_pairs] separator-local site of each pair (ascending within a part) */
+    const int32_t *ent_ptr;    /* [n_pairs + 1] entries of A_pS of each pair                            */
+    const int32_t *ent_row;    /*   interior row (internal site index)                                  */
+    const double *ent_val;     /*   A[row][separator site]                                              */
+    const int32_t *node_ptr;   /* [n_sep + 1] pairs touching each separator site                        */
+    const int32_t *node_pair;  /*   pair ids, ascending                                                 */
+    const int32_t *ass_indptr; /* A_SS as CSR [n_sep, n_sep], sorted columns                            */
+    const int32_t *ass_indices;
+    const double *ass_data;
+    const int32_t *seg_ptr;    /* the way down, as in tdgl_substructure                                 */
+    const int64_t *seg_val;
+    const int32_t *seg_x;
+    const int32_t *seg_len;
+    const int64_t *g_off;      /* [n_parts] */
+    const int64_t *et_off;     /* [n_parts] */
+    int64_t gvec_off, n_vals;
+    const int64_t *e_off;      /* [n_parts] */
+    int64_t n_e;
+} tdgl_substructure_plan;
+int tdgl_poisson_build_substructure(tdgl_ctx *ctx, const tdgl_substructure_plan *plan, double *seconds);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);

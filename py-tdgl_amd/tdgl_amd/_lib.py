@@ -151,6 +151,35 @@ class Substructure(C.Structure):
     ]
 
 
+class SubstructurePlan(C.Structure):
+    _fields_ = [
+        ("n_interior", C.c_int64),
+        ("n_sep", C.c_int64),
+        ("n_parts", C.c_int32),
+        ("part_ptr", c_i32p),
+        ("sep_ptr", c_i32p),
+        ("sep_idx", c_i32p),
+        ("ent_ptr", c_i32p),
+        ("ent_row", c_i32p),
+        ("ent_val", c_f64p),
+        ("node_ptr", c_i32p),
+        ("node_pair", c_i32p),
+        ("ass_indptr", c_i32p),
+        ("ass_indices", c_i32p),
+        ("ass_data", c_f64p),
+        ("seg_ptr", c_i32p),
+        ("seg_val", C.POINTER(C.c_int64)),
+        ("seg_x", c_i32p),
+        ("seg_len", c_i32p),
+        ("g_off", C.POINTER(C.c_int64)),
+        ("et_off", C.POINTER(C.c_int64)),
+        ("gvec_off", C.c_int64),
+        ("n_vals", C.c_int64),
+        ("e_off", C.POINTER(C.c_int64)),
+        ("n_e", C.c_int64),
+    ]
+
+
 class ScreeningOptions(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_int32),
@@ -187,6 +216,7 @@ SIGNATURES = {
     "tdgl_poisson_set_dense_inverse": (C.c_int, [_CTX, c_f64p, C.c_int64]),
     "tdgl_poisson_build_dense_inverse": (C.c_int, [_CTX, c_f64p]),
     "tdgl_poisson_set_substructure": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
+    "tdgl_poisson_build_substructure": (C.c_int, [_CTX, C.POINTER(SubstructurePlan), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
     "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),

@@ -150,11 +150,11 @@ class TDGLContext:
     # -- Poisson set-up -------------------------------------------------------------------
     # meshes up to this many sites get the direct solve (one dense matrix-vector product per step,
     # `tdgl_poisson_set_dense_inverse`) unless build_poisson is told otherwise
-    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "16384"))
+    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "6144"))
     # ... and up to this many the substructured direct solve (`tdgl_poisson_set_substructure`): parts of
     # ~SUB_BLOCK sites with explicit inverses, a dense Schur complement on the separator
     SUB_MAX_SITES = int(__import__("os").environ.get("TDGL_SUB_MAX_SITES", "150000"))
-    SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "448"))
+    SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "320"))
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
@@ -182,32 +182,55 @@ class TDGLContext:
         """Switch the mu solve to the substructured direct solve (`tdgl_poisson_set_substructure`); the
         context must have been created with the substructure site order (mid-size meshes are).  Checked on a
         random right-hand side like `build_dense_inverse`; returns whether it is on."""
-        from .substructure import build_substructure, pack_for_device
+        import os
+
+        from .substructure import build_substructure, pack_for_device, plan_for_device
 
         if self._sub_part_ptr is None:
             raise ValueError("this context's site order is not a substructure order")
         if A is None:
             k = self._keep
             A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
-        with _Stopwatch(self.setup_times, "substructure_host"):
-            try:
-                sub = build_substructure(A, self._sub_part_ptr)
-            except (ValueError, np.linalg.LinAlgError):
-                return False
-            pk = pack_for_device(sub)
-        d = _lib.Substructure(
-            n_interior=pk["n_interior"], n_sep=pk["n_sep"], n_parts=pk["n_parts"], part_ptr=p_i32(pk["part_ptr"]),
-            seg_ptr=p_i32(pk["seg_ptr"]), seg_val=pk["seg_val"].ctypes.data_as(C.POINTER(C.c_int64)), seg_x=p_i32(pk["seg_x"]),
-            seg_len=p_i32(pk["seg_len"]), vals=p_f64(pk["vals"]), n_vals=len(pk["vals"]), sep_ptr=p_i32(pk["sep_ptr"]),
-            sep_idx=p_i32(pk["sep_idx"]), e_off=pk["e_off"].ctypes.data_as(C.POINTER(C.c_int64)), e_vals=p_f64(pk["e_vals"]),
-            n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=p_f64(pk["schur"]),
-        )
         sec = C.c_double(0.0)
-        status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(d), C.byref(sec))
+        p_i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        if not os.environ.get("TDGL_SUB_HOST"):
+            # the factors are formed on the device; the host only describes the structure
+            with _Stopwatch(self.setup_times, "substructure_host"):
+                try:
+                    pl = plan_for_device(A, self._sub_part_ptr)
+                except ValueError:
+                    return False
+            d = _lib.SubstructurePlan(
+                n_interior=pl["n_interior"], n_sep=pl["n_sep"], n_parts=pl["n_parts"], part_ptr=p_i32(pl["part_ptr"]),
+                sep_ptr=p_i32(pl["sep_ptr"]), sep_idx=p_i32(pl["sep_idx"]), ent_ptr=p_i32(pl["ent_ptr"]), ent_row=p_i32(pl["ent_row"]),
+                ent_val=p_f64(pl["ent_val"]), node_ptr=p_i32(pl["node_ptr"]), node_pair=p_i32(pl["node_pair"]),
+                ass_indptr=p_i32(pl["ass_indptr"]), ass_indices=p_i32(pl["ass_indices"]), ass_data=p_f64(pl["ass_data"]),
+                seg_ptr=p_i32(pl["seg_ptr"]), seg_val=p_i64(pl["seg_val"]), seg_x=p_i32(pl["seg_x"]), seg_len=p_i32(pl["seg_len"]),
+                g_off=p_i64(pl["g_off"]), et_off=p_i64(pl["et_off"]), gvec_off=pl["gvec_off"], n_vals=pl["n_vals"],
+                e_off=p_i64(pl["e_off"]), n_e=pl["n_e"],
+            )
+            status = self._lib.tdgl_poisson_build_substructure(self._ctx, C.byref(d), C.byref(sec))
+            info = dict(parts=pl["parts"], separator=pl["separator"], bytes_per_solve=pl["bytes_per_solve"], built_on="device")
+        else:
+            with _Stopwatch(self.setup_times, "substructure_host"):
+                try:
+                    sub = build_substructure(A, self._sub_part_ptr)
+                except (ValueError, np.linalg.LinAlgError):
+                    return False
+                pk = pack_for_device(sub)
+            d = _lib.Substructure(
+                n_interior=pk["n_interior"], n_sep=pk["n_sep"], n_parts=pk["n_parts"], part_ptr=p_i32(pk["part_ptr"]),
+                seg_ptr=p_i32(pk["seg_ptr"]), seg_val=p_i64(pk["seg_val"]), seg_x=p_i32(pk["seg_x"]),
+                seg_len=p_i32(pk["seg_len"]), vals=p_f64(pk["vals"]), n_vals=len(pk["vals"]), sep_ptr=p_i32(pk["sep_ptr"]),
+                sep_idx=p_i32(pk["sep_idx"]), e_off=p_i64(pk["e_off"]), e_vals=p_f64(pk["e_vals"]),
+                n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=p_f64(pk["schur"]),
+            )
+            status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(d), C.byref(sec))
+            info = dict(parts=sub.n_parts, separator=sub.n_sep, bytes_per_solve=sub.bytes_per_solve(), built_on="host")
         if status != _lib.TDGL_OK:
             return False
         self.setup_times["substructure_device"] = sec.value
-        self.substructure = dict(parts=sub.n_parts, separator=sub.n_sep, bytes_per_solve=sub.bytes_per_solve())
+        self.substructure = info
         self.dense_direct = True
         b = np.random.default_rng(0).standard_normal(self.n)
         _, _, relres = self.poisson_solve(b)

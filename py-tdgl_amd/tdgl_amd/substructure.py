@@ -27,6 +27,8 @@ separator's dense inverse stops fitting the time budget (~150k sites).
 from dataclasses import dataclass
 from typing import List
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -92,29 +94,48 @@ def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray) -> Substructure:
     nS = n - nI
     if nS < 2:
         raise ValueError("substructure: no separator (a single part?)")
-    ASS = A[nI:, nI:].toarray()
-    schur = ASS
-    G, E, sidx = [], [], []
+    schur = A[nI:, nI:].toarray()
+    AIS = A[:nI, nI:].tocsr()
+    AII = A[:nI, :nI].tocsr()
     g = np.empty(nI)
     u = np.zeros(nS)
-    AIS = A[:nI, nI:].tocsr()
-    for p in range(P):
+
+    def one_part(p):
         a, b = int(part_ptr[p]), int(part_ptr[p + 1])
-        App = A[a:b, a:b].toarray()
+        App = AII[a:b, a:b].toarray()
         # (cross-part couplings between interiors do not exist: the separator covers every cut edge)
-        Gp = np.linalg.inv(App)
+        Gp = np.linalg.inv(App)  # (positive definite: a part's interior is a proper piece of a connected graph)
+        if not np.all(np.isfinite(Gp)) or np.any(np.diag(Gp) <= 0.0):
+            raise np.linalg.LinAlgError(f"part {p}: interior block not positive definite")
         Gp = 0.5 * (Gp + Gp.T)
         ApS = AIS[a:b]
         cols = np.unique(ApS.indices)
-        Ep = Gp @ ApS[:, cols].toarray()
-        schur[np.ix_(cols, cols)] -= ApS[:, cols].toarray().T @ Ep
-        G.append(np.ascontiguousarray(Gp))
-        E.append(np.ascontiguousarray(Ep))
-        sidx.append(cols.astype(np.int32))
+        B = ApS[:, cols].toarray()
+        Ep = Gp @ B
+        return Gp, np.ascontiguousarray(Ep), cols.astype(np.int32), B.T @ Ep
+
+    # the parts are independent: a thread each (LAPACK / BLAS release the GIL; one BLAS thread per call)
+    from concurrent.futures import ThreadPoolExecutor
+
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        from contextlib import nullcontext as threadpool_limits
+    workers = max(1, min(32, (os.cpu_count() or 1)))
+    with threadpool_limits(limits=1):
+        with ThreadPoolExecutor(workers) as pool:
+            results = list(pool.map(one_part, range(P)))
+    G, E, sidx = [], [], []
+    for p, (Gp, Ep, cols, C) in enumerate(results):
+        a, b = int(part_ptr[p]), int(part_ptr[p + 1])
+        schur[np.ix_(cols, cols)] -= C
+        G.append(Gp)
+        E.append(Ep)
+        sidx.append(cols)
         g[a:b] = Gp.sum(axis=1)
         u[cols] -= Ep.sum(axis=0)
     # interiors of different parts must not be coupled
-    off = A[:nI, :nI].tocoo()
+    off = AII.tocoo()
     pr = np.searchsorted(part_ptr, off.row, side="right")
     pc = np.searchsorted(part_ptr, off.col, side="right")
     if np.any(pr != pc):
@@ -223,3 +244,77 @@ def down_host(pk, b):
             v0, x0, ln = int(pk["seg_val"][k]), int(pk["seg_x"][k]), int(pk["seg_len"][k])
             out[r] += pk["vals"][v0:v0 + ln] @ b[x0:x0 + ln]
     return out
+
+
+def plan_for_device(A: sp.spmatrix, part_ptr: np.ndarray):
+    """Index arrays of `tdgl_substructure_plan` (include/tdgl_hip.h): everything `tdgl_poisson_build_substructure`
+    needs to form the factors ON THE DEVICE -- which separator sites each part touches, the entries of
+    ``A_pS`` grouped by (part, separator site), the (part, site) pairs grouped by site, ``A_SS`` as CSR, and
+    the segment description of the way down with the offsets of the value pool the library fills
+    (``[1.0 | G_p blocks | -E_p^T blocks | G_p 1]``, as `pack_for_device` lays it out).  No floating point
+    work happens here."""
+    A = A.tocsr()
+    n = A.shape[0]
+    pp = np.asarray(part_ptr, dtype=np.int64)
+    P = len(pp) - 1
+    nI = int(pp[-1])
+    nS = n - nI
+    if nS < 2 or P < 1:
+        raise ValueError("substructure: no separator (a single part?)")
+    AII = A[:nI, :nI].tocoo()
+    pr = np.searchsorted(pp, AII.row, side="right")
+    pc = np.searchsorted(pp, AII.col, side="right")
+    if np.any(pr != pc):
+        raise ValueError("substructure: the separator does not cover every cut edge")
+    AIS = A[:nI, nI:].tocoo()
+    part_of = np.searchsorted(pp, AIS.row, side="right") - 1
+    key = part_of.astype(np.int64) * nS + AIS.col
+    order = np.argsort(key, kind="stable")
+    key, rows, vals = key[order], AIS.row[order], AIS.data[order]
+    pairs, start, counts = np.unique(key, return_index=True, return_counts=True)
+    pair_part = (pairs // nS).astype(np.int64)
+    sep_idx = (pairs % nS).astype(np.int32)
+    s_cnt = np.bincount(pair_part, minlength=P).astype(np.int64)
+    sep_ptr = np.concatenate([[0], np.cumsum(s_cnt)]).astype(np.int32)
+    ent_ptr = np.concatenate([start, [len(key)]]).astype(np.int32)
+    node_order = np.argsort(sep_idx, kind="stable")  # pairs grouped by separator site, ascending pair id
+    node_ptr = np.concatenate([[0], np.cumsum(np.bincount(sep_idx, minlength=nS))]).astype(np.int32)
+    ASS = A[nI:, nI:].tocsr()
+    ASS.sort_indices()
+    sizes = np.diff(pp)
+    g_off = 1 + np.concatenate([[0], np.cumsum(sizes * sizes)])
+    et_off = g_off[-1] + np.concatenate([[0], np.cumsum(sizes * s_cnt)])
+    gvec_off = int(et_off[-1])
+    e_off = np.concatenate([[0], np.cumsum(sizes * s_cnt)])
+    # segments of the way down (pack_for_device without the values)
+    rows_I = np.arange(nI, dtype=np.int64)
+    pof = np.searchsorted(pp, rows_I, side="right") - 1
+    seg_val = [g_off[pof] + (rows_I - pp[pof]) * sizes[pof], np.zeros(nS, dtype=np.int64)]
+    seg_x = [pp[pof], nI + np.arange(nS, dtype=np.int64)]
+    seg_len = [sizes[pof], np.ones(nS, dtype=np.int64)]
+    seg_row = [rows_I, nI + np.arange(nS, dtype=np.int64)]
+    jloc = np.arange(len(pairs), dtype=np.int64) - sep_ptr[pair_part]
+    seg_val.append(et_off[pair_part] + jloc * sizes[pair_part])
+    seg_x.append(pp[pair_part])
+    seg_len.append(sizes[pair_part])
+    seg_row.append(nI + sep_idx.astype(np.int64))
+    seg_val.append(gvec_off + pp[:-1])
+    seg_x.append(pp[:-1])
+    seg_len.append(sizes)
+    seg_row.append(n + np.arange(P, dtype=np.int64))
+    seg_val, seg_x, seg_len, seg_row = (np.concatenate(a) for a in (seg_val, seg_x, seg_len, seg_row))
+    o2 = np.argsort(seg_row, kind="stable")
+    seg_ptr = np.concatenate([[0], np.cumsum(np.bincount(seg_row, minlength=n + P))]).astype(np.int32)
+    c = np.ascontiguousarray
+    return dict(
+        n_interior=nI, n_sep=nS, n_parts=P, part_ptr=c(pp.astype(np.int32)), sep_ptr=c(sep_ptr), sep_idx=c(sep_idx),
+        ent_ptr=c(ent_ptr), ent_row=c(rows.astype(np.int32)), ent_val=c(vals.astype(np.float64)),
+        node_ptr=c(node_ptr), node_pair=c(node_order.astype(np.int32)),
+        ass_indptr=c(ASS.indptr.astype(np.int32)), ass_indices=c(ASS.indices.astype(np.int32)), ass_data=c(ASS.data.astype(np.float64)),
+        seg_ptr=c(seg_ptr), seg_val=c(seg_val[o2].astype(np.int64)), seg_x=c(seg_x[o2].astype(np.int32)),
+        seg_len=c(seg_len[o2].astype(np.int32)), g_off=c(g_off[:-1].astype(np.int64)), et_off=c(et_off[:-1].astype(np.int64)),
+        gvec_off=gvec_off, n_vals=gvec_off + nI, e_off=c(e_off[:-1].astype(np.int64)), n_e=int(e_off[-1]),
+        max_sep=int(s_cnt.max()), parts=P, separator=nS,
+        bytes_per_solve=int(8 * ((sizes * sizes).sum() + 2 * (sizes * s_cnt).sum())
+                            + 8 * ((nS + 127) // 128) * (((nS + 127) // 128) + 1) // 2 * 128 * 128),
+    )
