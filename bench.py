@@ -50,6 +50,8 @@ WORKLOADS = {
     "12k": (101.0, "square film 101 xi, ~12k sites"),
     "16k": (117.0, "square film 117 xi, ~16k sites"),
     "23k": (140.0, "square film 140 xi, ~23k sites"),
+    "120k": (320.0, "square film 320 xi, ~120k sites"),
+    "160k": (370.0, "square film 370 xi, ~160k sites"),
     "60k": (226.0, "square film 226 xi, 59,377 sites"),
     "250k": (465.0, "square film 465 xi, 250,510 sites"),
     "1M": (930.0, "square film 930 xi, 1,000,431 sites"),

@@ -278,7 +278,7 @@ struct tdgl_ctx {
     int32_t sub_parts = 0;                // > 0: in use
     int64_t sub_nI = 0, sub_nS = 0;
     tdgl::DevBuf<int32_t> sub_part_ptr, sub_seg_ptr, sub_seg_x, sub_seg_len, sub_sep_ptr, sub_sep_idx, sub_row_part;
-    tdgl::DevBuf<int64_t> sub_seg_val, sub_e_off;
+    tdgl::DevBuf<int64_t> sub_seg_val, sub_e_off, sub_g_off;
     tdgl::DevBuf<double> sub_vals, sub_e, sub_u;
     tdgl::DevBuf<double> sub_w;           // [n + parts] result of the way down
     tdgl::DevBuf<double> sub_xs;          // [n_sep] separator solution before the mean is removed

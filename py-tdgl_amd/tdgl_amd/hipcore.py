@@ -99,7 +99,8 @@ class TDGLContext:
 
                     rank = np.empty(self.n, dtype=np.int64)
                     rank[perm] = np.arange(self.n)
-                    perm, self._sub_part_ptr = substructure_order(np.asarray(mesh.sites), em.edges, self.SUB_BLOCK, rank_hint=rank)
+                    block = self.SUB_BLOCK or max(320, int(320 * (self.n / 60000.0) ** (2.0 / 3.0)))
+                    perm, self._sub_part_ptr = substructure_order(np.asarray(mesh.sites), em.edges, block, rank_hint=rank)
         elif reorder is None or reorder == "none":
             perm = np.arange(self.n, dtype=np.int32)
         else:
@@ -154,7 +155,9 @@ class TDGLContext:
     # ... and up to this many the substructured direct solve (`tdgl_poisson_set_substructure`): parts of
     # ~SUB_BLOCK sites with explicit inverses, a dense Schur complement on the separator
     SUB_MAX_SITES = int(__import__("os").environ.get("TDGL_SUB_MAX_SITES", "150000"))
-    SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "320"))
+    # (0 = by size: 320 sites per part up to 60k sites, growing like n^(2/3) beyond -- the dense Schur
+    # complement of the separator, ~2 n / sqrt(block) sites, is what grows fastest)
+    SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "0"))
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
