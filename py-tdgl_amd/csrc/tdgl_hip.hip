@@ -159,6 +159,8 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (ctx->h_sendbuf) (void)hipHostFree(ctx->h_sendbuf);
     if (ctx->h_recvbuf) (void)hipHostFree(ctx->h_recvbuf);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
+    if (ctx->h_rec) (void)hipHostFree(ctx->h_rec);
     if (ctx->h_probe_out) (void)hipHostFree(ctx->h_probe_out);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -367,6 +369,10 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
         HIP_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_dev), ctx->h_status, 0));
     }
     HIP_TRY(ctx, ctx->scal.alloc(S_COUNT));
+    HIP_TRY(ctx, ctx->d_ctl.alloc(1));
+    HIP_TRY(ctx, ctx->d_rec.alloc(RA_BATCH_MAX));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_ctl), sizeof(StepCtl)));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_rec), RA_BATCH_MAX * sizeof(StepRec)));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev0));
     HIP_TRY(ctx, hipEventCreate(&ctx->ev1));
     ctx->psi_blocks = (int)std::min<int64_t>(std::max<int64_t>(grid_for(ctx->n_own), 1), 2048);
@@ -497,11 +503,12 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
 
 // ... with the edge currents of the step just accepted in the same launch (k_psi_update_with_currents)
 static void launch_psi_update_with_currents(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
-                                            double dt, double2 *psi_new) {
-    hipLaunchKernelGGL(k_psi_update_with_currents, dim3(ctx->psi_blocks + grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream,
+                                            double dt, double2 *psi_new, bool with_currents = true, StepCtl *ctl = nullptr) {
+    const int64_t m = with_currents ? ctx->m : 0;
+    hipLaunchKernelGGL(k_psi_update_with_currents, dim3(ctx->psi_blocks + (m > 0 ? grid_for(m) : 0)), dim3(BLOCK), 0, ctx->stream,
                        ctx->psi_blocks, ctx->n_own, psi, mu, ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new,
-                       ctx->psi_dmax_part.p, ctx->psi_fail_part.p, ctx->m, ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p,
-                       ctx->e_U.p, ctx->js.p, ctx->jn.p);
+                       ctx->psi_dmax_part.p, ctx->psi_fail_part.p, m, ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p,
+                       ctx->e_U.p, ctx->js.p, ctx->jn.p, ctl);
     ctx->psi_status_pending = true;
 }
 

@@ -149,6 +149,32 @@ struct XrArgs {
 
 constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels.inc: GK)
 
+// Run-ahead time loop of the direct solves (run.inc: run_ahead): the adaptive-dt controller and the loop's
+// bookkeeping live on the device, so that the host can queue a batch of steps without waiting for each
+// step's outcome.  `poisoned` stops everything behind a failed psi update (the host repeats that step the
+// classic way with a smaller dt) or behind the step that reached end_time.
+constexpr int RA_HIST_MAX = 128;   // adaptive_window up to here (numpy's pairwise sum has no recursion below 129 terms)
+constexpr int RA_BATCH_MAX = 64;
+struct StepCtl {
+    double tentative_dt;   // dt of the next attempt (solver.py:316-320, 698-707)
+    double time;           // Runner.time (runner.py:433)
+    double end_time;
+    double dt_init, dt_cap;
+    long long stage_step;  // Runner step index of the current stage
+    int adaptive, window;
+    int poisoned;          // no further step may run
+    int live;              // the step being processed started un-poisoned (set by its psi-update kernel)
+    int reached_end;
+    int n_done;            // steps processed since the batch began (accepted ones first, at most one failed last)
+    int hist_count;
+    int pad;
+    double hist[RA_HIST_MAX];  // the last min(window, count) values of max d|psi|^2, oldest first
+};
+struct StepRec {
+    double dt, dmax;
+    int ok, pad;
+};
+
 struct StepStatus {
     int32_t fail_flag;          // psi update: discriminant < 0 or non-finite somewhere
     int32_t pad;
@@ -284,6 +310,13 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> sub_xs;          // [n_sep] separator solution before the mean is removed
     tdgl::DevBuf<double> sub_upart;       // per-workgroup partials of u . x_S
     int sub_nfin = 0;                     // workgroups of k_dense_sym_finish
+    // run-ahead time loop (direct solves, static links): device-resident controller + per-step records
+    tdgl::DevBuf<tdgl::StepCtl> d_ctl;
+    tdgl::DevBuf<tdgl::StepRec> d_rec;
+    tdgl::StepCtl *h_ctl = nullptr;       // pinned
+    tdgl::StepRec *h_rec = nullptr;       // pinned [RA_BATCH_MAX]
+    int ra_batch = 4;                     // grows while no psi update fails, shrinks after one
+    int64_t stat_ra_batches = 0, stat_ra_dead = 0;
     bool currents_deferred = false;       // J of the last accepted step ride in the next step's psi-update launch
     bool spec_currents = false;           // step driver: queue the edge currents right behind the dense solve,
     bool spec_currents_done = false;      // before the host has seen the step's status (run.inc)
