@@ -503,13 +503,36 @@ static void launch_psi_update(tdgl_ctx *ctx, const double2 *psi, const double *m
 
 // ... with the edge currents of the step just accepted in the same launch (k_psi_update_with_currents)
 static void launch_psi_update_with_currents(tdgl_ctx *ctx, const double2 *psi, const double *mu, const double2 *lap,
-                                            double dt, double2 *psi_new, bool with_currents = true, StepCtl *ctl = nullptr) {
-    const int64_t m = with_currents ? ctx->m : 0;
-    hipLaunchKernelGGL(k_psi_update_with_currents, dim3(ctx->psi_blocks + (m > 0 ? grid_for(m) : 0)), dim3(BLOCK), 0, ctx->stream,
+                                            double dt, double2 *psi_new) {
+    hipLaunchKernelGGL(k_psi_update_with_currents, dim3(ctx->psi_blocks + grid_for(ctx->m)), dim3(BLOCK), 0, ctx->stream,
                        ctx->psi_blocks, ctx->n_own, psi, mu, ctx->eps.p, lap, dt, ctx->u, ctx->gamma, psi_new,
-                       ctx->psi_dmax_part.p, ctx->psi_fail_part.p, m, ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p,
-                       ctx->e_U.p, ctx->js.p, ctx->jn.p, ctl);
+                       ctx->psi_dmax_part.p, ctx->psi_fail_part.p, ctx->m, ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p,
+                       ctx->e_U.p, ctx->js.p, ctx->jn.p);
     ctx->psi_status_pending = true;
+}
+
+// one attempt of the run-ahead loop: psi update (+ the owed edge currents) ...
+static void launch_ra_psi(tdgl_ctx *ctx, bool with_currents) {
+    const int64_t m = with_currents ? ctx->m : 0;
+    hipLaunchKernelGGL(k_ra_psi_update, dim3(ctx->psi_blocks + (m > 0 ? grid_for(m) : 0)), dim3(BLOCK), 0, ctx->stream,
+                       ctx->psi_blocks, ctx->n_own, ctx->psi[0].p, ctx->psi[1].p, (const double2 *)ctx->lap[0].p,
+                       (const double2 *)ctx->lap[1].p, (const double *)ctx->mu.p, (const double *)ctx->eps.p, ctx->u, ctx->gamma,
+                       ctx->psi_dmax_part.p, ctx->psi_fail_part.p, m, ctx->e0.p, ctx->e1.p, ctx->e_inv_len.p, ctx->e_U.p,
+                       ctx->js.p, ctx->jn.p, ctx->d_ctl.p);
+}
+
+// ... then L psi' and the right-hand side
+static void launch_ra_laplacian(tdgl_ctx *ctx) {
+    const SellPattern &pat = ctx->lap_pat;
+    const int tiles = (pat.n_slices + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+    const int per_xcd = (tiles + XCDS - 1) / XCDS, grid = per_xcd * XCDS;
+#define TDGL_K1RA(IT, COLS)                                                                                          \
+    hipLaunchKernelGGL((k_psi_laplacian_ra<IT>), dim3(grid), dim3(BLOCK), 0, ctx->stream, pat.n_slices, per_xcd, pat.n_rows, \
+                       pat.slice_off.p, COLS, ctx->lap_vals.p, ctx->lap_diag.p, ctx->fixed_mask.p,                   \
+                       (const double2 *)ctx->psi[0].p, (const double2 *)ctx->psi[1].p, ctx->lap[0].p, ctx->lap[1].p, \
+                       ctx->area.p, (const double *)ctx->ceff.p, ctx->bvec.p, (const StepCtl *)ctx->d_ctl.p)
+    if (pat.use16) TDGL_K1RA(int16_t, pat.cols16.p); else TDGL_K1RA(int32_t, pat.cols.p);
+#undef TDGL_K1RA
 }
 
 // reduce the outcome of the last psi update into d_status (together with the PCG scalars);
@@ -815,6 +838,8 @@ extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu
     ctx->have_state = true;
     ctx->lap_valid = false;
     ctx->currents_valid = false;
+    ctx->currents_deferred = false;
+    ctx->ra_retries = 0;
     ctx->prev_dt = ctx->prev_dt2 = 0.0;  // no mu history: the next solve starts from mu itself
     ctx->g_count = 0;                     // (nor a projection basis)
     ctx->g_diag_pending = false;

@@ -156,16 +156,21 @@ constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels
 constexpr int RA_HIST_MAX = 128;   // adaptive_window up to here (numpy's pairwise sum has no recursion below 129 terms)
 constexpr int RA_BATCH_MAX = 64;
 struct StepCtl {
-    double tentative_dt;   // dt of the next attempt (solver.py:316-320, 698-707)
+    double tentative_dt;   // dt the next STEP starts from (solver.py:316-320, 698-707)
+    double attempt_dt;     // dt of the next attempt: tentative_dt, times the multiplier per failed attempt of the step
     double time;           // Runner.time (runner.py:433)
     double end_time;
-    double dt_init, dt_cap;
+    double dt_init, dt_cap, multiplier;
     long long stage_step;  // Runner step index of the current stage
-    int adaptive, window;
-    int poisoned;          // no further step may run
-    int live;              // the step being processed started un-poisoned (set by its psi-update kernel)
-    int reached_end;
-    int n_done;            // steps processed since the batch began (accepted ones first, at most one failed last)
+    int adaptive, window, max_retries;
+    int cur;               // which psi / L psi buffer holds psi^n
+    int retries;           // failed attempts of the current step so far
+    int poisoned;          // no further attempt may run (end reached, or the retry budget is spent)
+    int live;              // the attempt being processed started un-poisoned (set by its psi-update kernel)
+    int last_ok;           // ... and was accepted
+    int reached_end, error;
+    int n_done;            // attempts processed since the batch began
+    int n_acc;             // ... of which accepted
     int hist_count;
     int pad;
     double hist[RA_HIST_MAX];  // the last min(window, count) values of max d|psi|^2, oldest first
@@ -315,7 +320,9 @@ struct tdgl_ctx {
     tdgl::DevBuf<tdgl::StepRec> d_rec;
     tdgl::StepCtl *h_ctl = nullptr;       // pinned
     tdgl::StepRec *h_rec = nullptr;       // pinned [RA_BATCH_MAX]
-    int ra_batch = 4;                     // grows while no psi update fails, shrinks after one
+    int ra_batch = 4;                     // attempts queued per synchronisation: doubles up to RA_BATCH_MAX
+    int ra_retries = 0;                   // failed attempts of the step in progress when the last batch ended ...
+    double ra_attempt_dt = 0.0;           // ... and the dt its next attempt takes (the retry state outlives a batch)
     int64_t stat_ra_batches = 0, stat_ra_dead = 0;
     bool currents_deferred = false;       // J of the last accepted step ride in the next step's psi-update launch
     bool spec_currents = false;           // step driver: queue the edge currents right behind the dense solve,
