@@ -2,10 +2,10 @@
 # run-ahead time loop: tests (direct suite + the full suite), steps/s with / without it over sizes
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_hip_direct.py -x -q -m gpu 2>&1 | tail -6
+timeout 300 python -m pytest tests/test_hip_direct.py -x -q -m gpu 2>&1 | tail -3
 : > $OUT/AB_r03_ra.jsonl
 run() {
-    env $2 timeout 600 python bench.py --workload $1 --no-cpu-baseline --steps 2000 --warmup 200 > $OUT/tmp_line.json 2> $OUT/r03_ra.err
+    env $2 timeout 150 python bench.py --workload $1 --no-cpu-baseline --steps 2000 --warmup 200 > $OUT/tmp_line.json 2> $OUT/r03_ra.err
     echo "$1 $2 rc=$?"; tail -1 $OUT/r03_ra.err | cut -c1-200
     cat $OUT/tmp_line.json >> $OUT/AB_r03_ra.jsonl
     python - <<'PY'
