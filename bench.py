@@ -46,6 +46,7 @@ WORKLOADS = {
     "5k": (70.0, "square film 70 xi, 5,791 sites"),
     # sizes around the switch between the direct (dense) and the iterative mu solve
     "2k": (42.0, "square film 42 xi, ~2.1k sites"),
+    "4k": (58.0, "square film 58 xi, ~4k sites"),
     "9k": (88.0, "square film 88 xi, ~9k sites"),
     "12k": (101.0, "square film 101 xi, ~12k sites"),
     "16k": (117.0, "square film 117 xi, ~16k sites"),
