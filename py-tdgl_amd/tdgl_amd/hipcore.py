@@ -99,7 +99,7 @@ class TDGLContext:
 
                     rank = np.empty(self.n, dtype=np.int64)
                     rank[perm] = np.arange(self.n)
-                    block = self.SUB_BLOCK or max(320, int(320 * (self.n / 60000.0) ** (2.0 / 3.0)))
+                    block = self.SUB_BLOCK or (192 if self.n <= 8000 else max(320, int(320 * (self.n / 60000.0) ** (2.0 / 3.0))))
                     perm, self._sub_part_ptr = substructure_order(np.asarray(mesh.sites), em.edges, block, rank_hint=rank)
         elif reorder is None or reorder == "none":
             perm = np.arange(self.n, dtype=np.int32)
@@ -151,12 +151,12 @@ class TDGLContext:
     # -- Poisson set-up -------------------------------------------------------------------
     # meshes up to this many sites get the direct solve (one dense matrix-vector product per step,
     # `tdgl_poisson_set_dense_inverse`) unless build_poisson is told otherwise
-    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "6144"))
+    DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "5000"))
     # ... and up to this many the substructured direct solve (`tdgl_poisson_set_substructure`): parts of
     # ~SUB_BLOCK sites with explicit inverses, a dense Schur complement on the separator
     SUB_MAX_SITES = int(__import__("os").environ.get("TDGL_SUB_MAX_SITES", "150000"))
-    # (0 = by size: 320 sites per part up to 60k sites, growing like n^(2/3) beyond -- the dense Schur
-    # complement of the separator, ~2 n / sqrt(block) sites, is what grows fastest)
+    # (0 = by size: 192 sites per part up to 8k sites, 320 up to 60k, growing like n^(2/3) beyond -- the dense
+    # Schur complement of the separator, ~2 n / sqrt(block) sites, is what grows fastest)
     SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "0"))
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,

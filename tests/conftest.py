@@ -53,7 +53,7 @@ def _iterative_mu_solve_unless_asked():
 def direct_solve(monkeypatch):
     from tdgl_amd.hipcore import TDGLContext
 
-    assert _PRODUCT_DENSE_MAX_SITES >= 5800 and _PRODUCT_SUB_MAX_SITES >= 60000  # the product defaults cover the reference's documented mesh sizes
+    assert _PRODUCT_DENSE_MAX_SITES >= 4000 and _PRODUCT_SUB_MAX_SITES >= 60000  # the product defaults cover the reference's documented mesh sizes
     monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", _PRODUCT_DENSE_MAX_SITES)
     monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", _PRODUCT_SUB_MAX_SITES)
     return _PRODUCT_DENSE_MAX_SITES
