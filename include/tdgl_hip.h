@@ -458,7 +458,12 @@ int tdgl_begin_stage(tdgl_ctx *ctx);
  *                        "screening_iterations", solver.py:695-696)       (may be NULL)
  *   steps_done           iterations executed
  *   reached_end          1 if the loop ended because time >= end_time
- * Returns TDGL_ERR_PSI_RETRIES with the reference's message when the psi update fails. */
+ * Returns TDGL_ERR_PSI_RETRIES with the reference's message when the psi update fails.
+ * With a direct mu solve (tdgl_poisson_build_dense_inverse / _build_substructure), static link variables,
+ * no tables and no screening the loop runs AHEAD of the host: the retry decision (solver.py:475-485), the
+ * adaptive-dt controller (:698-707) and this loop's bookkeeping execute on the device and the host
+ * synchronises once per batch of up to 64 attempts -- outputs, errors and the state left behind are
+ * bit-identical to the one-synchronisation-per-step loop (environment TDGL_NO_RUN_AHEAD=1 forces that one). */
 int tdgl_run(tdgl_ctx *ctx, int64_t max_steps, double end_time, double *out_dt,
              double *out_mu_probe, double *out_theta_probe, int32_t *out_pcg_iters,
              int64_t *steps_done, int32_t *reached_end, int32_t *out_screening_iters);
