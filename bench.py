@@ -633,6 +633,24 @@ def main():
             algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=main_run.axp[0],
             event_pair_overhead_ms=round(main_run.ev_over, 5),
         )
+    # direct mu solves (small / mid-size workloads): the solve's launches (k_dense_sym_tiles + k_dense_sym_finish, or
+    # k_sub_down + those two + k_sub_up) bracketed by one event pair per batch of the run-ahead loop; bytes = the factors
+    # streamed once per solve (the symmetric packing halves the dense inverse: what is moved, not n^2 * 8)
+    roofline_direct = None
+    if rank == 0 and main_run.axp[0] > 0 and main_run.setup.get("mu_solver", "amg_pcg") != "amg_pcg":
+        roofline_pcg = None
+        sub = getattr(main_run.ctx, "substructure", None)
+        nt = (main_run.n + 127) // 128
+        solve_bytes = int(sub["bytes_per_solve"]) if sub else nt * (nt + 1) // 2 * 128 * 128 * 8
+        avg_ms = main_run.axp[1] / main_run.axp[0]
+        roofline_direct = dict(
+            bound="hbm", kernel="direct mu solve: " + ("k_sub_down + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up" if sub else
+                                                       "k_dense_sym_tiles + k_dense_sym_finish"),
+            achieved=round(solve_bytes / (avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(solve_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), bytes_per_solve=solve_bytes,
+            avg_solve_ms=round(avg_ms, 5), samples=main_run.axp[0], event_pair_overhead_ms=round(main_run.ev_over, 5),
+            note="launch sequence bracketed by one HIP event pair per batch of the run-ahead loop (the pair's own overhead included)",
+        )
     r = main_run
     desc = WORKLOADS[args.workload][1]
     strip = isinstance(WORKLOADS[args.workload][0], tuple)
@@ -663,6 +681,7 @@ def main():
         ),
         roofline=main_line["roofline"],
         roofline_pcg=roofline_pcg,
+        roofline_direct=roofline_direct,
         pcg=main_line["pcg"],
         step_aggregate=main_line["step_aggregate"],
         # what a step costs the host: synchronisations and repeated psi updates in the timed window
