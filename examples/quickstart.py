@@ -29,7 +29,8 @@ solution = tdgl.solve(device, options, applied_vector_potential=0.4,
 
 dyn = solution.dynamics
 print(f"{solution.stats['steps_thermalizing']} + {solution.stats['steps_simulating']} steps in "
-      f"{solution.total_seconds:.2f} s, {solution.stats['mean_pcg_iterations']:.1f} PCG iterations per step")
+      f"{solution.total_seconds:.2f} s; mu solve: {solution.stats['mu_solver']}"
+      + (f", {solution.stats['mean_pcg_iterations']:.1f} PCG iterations per step" if solution.stats['mu_solver'] == "amg_pcg" else ""))
 print(f"saved steps: {len(solution.saved_steps)}; min |psi| = {np.abs(solution.tdgl_data.psi).min():.3f}")
 print(f"mean voltage between the probes: {dyn.voltage().mean():.4f} V0")
 print(f"current through the cut x = 1.5: {solution.current_through_cut(1.5, physical=True):.3f} uA (injected: 12)")

@@ -608,6 +608,9 @@ class TDGLSolver:
                 steps_thermalizing=n_steps["Thermalizing"],
                 steps_simulating=n_steps["Simulating"],
                 mean_pcg_iterations=float(dynamics.pcg_iterations.mean()) if len(dynamics.pcg_iterations) else 0.0,
+                # which mu solve the mesh size selected (hipcore.TDGLContext.build_poisson)
+                mu_solver=("direct (substructured)" if getattr(self.ctx, "substructure", None) else
+                           "direct (dense inverse)" if getattr(self.ctx, "dense_direct", False) else "amg_pcg"),
             ),
         )
         if handler is not None:
