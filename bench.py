@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--extrapolate", type=int, default=3,
                     help="initial guess of the mu solve: 0 previous, 1/2 linear/quadratic extrapolation in time, "
                          "3 projection onto the last --guess-window solutions")
-    ap.add_argument("--guess-window", type=int, default=6)
+    ap.add_argument("--guess-window", type=int, default=0, help="window of the projection guess, 1..16 (0 = library default, 12)")
     ap.add_argument("--cheb-lo", type=float, default=0.1, help="Chebyshev smoothing interval [cheb_lo * rho, rho]")
     ap.add_argument("--precond-fp64", action="store_true",
                     help="keep the level-0 operators of the V-cycle in fp64 (default: fp32 storage inside the fp64 CG)")

@@ -105,9 +105,9 @@ typedef struct {
     double cheb_lo;       /* Chebyshev interval [cheb_lo * rho, rho]                   */
     int32_t extrapolate;  /* initial guess: 0 = mu^n, 1 = linear, 2 = quadratic extrapolation
                              in time through the last two / three solutions, 3 (default) = the
-                             A-norm projection of the solution onto the span of the last
-                             guess_window solutions (the matrix is the same every step):
-                             ~40x smaller initial residual than the quadratic extrapolation  */
+                             combination of the last guess_window solutions with the smallest
+                             residual (the matrix is the same every step; dot products and the
+                             small solve in double-double arithmetic, see tdgl_get_guess_gram)  */
     int32_t nu_fine;      /* smoother degree on level 0 (0 = nu).  Default 1 with nu = 2:
                              halves the level-0 passes per cycle for ~5 % more iterations  */
     int32_t precond_fp32; /* 1 (default): the operators of the V-cycle (level 0: fused restriction,
@@ -122,7 +122,7 @@ typedef struct {
                              (fused restriction, prolongation, the matrix of the smoothing step)
                              are stored in IEEE binary16 -- same PCG iteration count; falls back
                              to 1 when an entry exceeds binary16's range.  0: everything fp64.  */
-    int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..8 (0 = 6)   */
+    int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..16 (0 = 12) */
     int32_t flexible_cg;  /* 1: beta = z_{k+1}.(r_{k+1} - r_k) / z_k.r_k (Polak-Ribiere, the "flexible" CG), which
                              tolerates a preconditioner that is not exactly symmetric -- the V-cycle's
                              operators are rounded to fp32 / binary16 one by one.  0 (default): beta =
@@ -302,13 +302,17 @@ int tdgl_get_precond_storage(tdgl_ctx *ctx, int32_t *mode);
 /* Quality of the last solve's initial guess: number of basis vectors it was projected on
  * (extrapolate = 3; 0 = none) and ||b - A x0|| / ||b||. */
 int tdgl_get_guess_stats(tdgl_ctx *ctx, int32_t *vectors, double *initial_relres);
-/* The Gram matrix G_ij = x_i . b_j of the projection guess's window (k <= 8 vectors, row-major
- * [k, k], oldest first; a diagonal entry still travelling with the next status block reads 0):
- * a global quantity, identical on every rank of a decomposed run (tests). */
+/* The Gram matrix G_ij = y_i . y_j of the projection guess's window, y_j = A x_j (k <= 16 vectors,
+ * row-major [k, k], oldest first, rounded to fp64 from the double-double sums the library keeps; the
+ * newest vector's row and column are exact only after the next solve has started -- until then they
+ * hold y_j . b_newest): a global quantity, identical on every rank of a decomposed run (tests). */
 int tdgl_get_guess_gram(tdgl_ctx *ctx, int32_t *k, double *G_rowmajor);
-/* Host-only: c = pinv(G) rhs for the k x k Gram matrix of the projection guess (eigen-decomposition,
- * directions below 1e-13 of the largest eigenvalue dropped).  No device work. */
-int tdgl_host_solve_gram(int32_t k, const double *G_rowmajor, const double *rhs, double *c);
+/* Host-only: c = argmin ||b - Y c||_2 from G = Y^T Y and g = Y^T b given as double-double (hi, lo) pairs
+ * (G_pairs [k, k, 2], g_pairs [k, 2], oldest vector first): L D L^T in double-double arithmetic from the
+ * newest vector to the oldest; a vector whose pivot is below cut * G_jj is left out (c_j = 0).
+ * *used (may be NULL) = vectors kept.  No device work. */
+int tdgl_host_solve_gram(int32_t k, const double *G_pairs, const double *g_pairs, double cut, double *c,
+                         int32_t *used);
 
 /* ------------------------------------------------------------------ one process per GPU
  * The reference is single-process.  Here the mesh is cut into `world` pieces (host layer:

@@ -544,7 +544,7 @@ static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
                        ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
-                       guess_start ? ctx->part_gdot.p : (const double *)nullptr, (double)ctx->n_global,
+                       guess_start ? ctx->part_gdot.p : (const double *)nullptr, ctx->g_count, (double)ctx->n_global,
                        ctx->popt.rtol * ctx->popt.rtol, rr_part);
     ctx->psi_status_pending = false;
 }
@@ -842,7 +842,7 @@ extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu
     ctx->ra_retries = 0;
     ctx->prev_dt = ctx->prev_dt2 = 0.0;  // no mu history: the next solve starts from mu itself
     ctx->g_count = 0;                     // (nor a projection basis)
-    ctx->g_diag_pending = false;
+    ctx->g_row_pending = false;
     return TDGL_OK;
 }
 

@@ -147,7 +147,7 @@ struct XrArgs {
     int npart;  // entries of every partial array in use (tdgl_ctx::npart)
 };
 
-constexpr int GUESS_MAX = 8;  // maximal window of the projection guess (kernels.inc: GK)
+constexpr int GUESS_MAX = 16;  // maximal window of the projection guess (kernels.inc: GK)
 
 // Run-ahead time loop of the direct solves (run.inc: run_ahead): the adaptive-dt controller and the loop's
 // bookkeeping live on the device, so that the host can queue a batch of steps without waiting for each
@@ -185,8 +185,9 @@ struct StepStatus {
     int32_t pad;
     unsigned long long dmax_bits[8];  // max | |psi'|^2 - |psi|^2 | as ordered uint64 bits, 8 slots
     double scal[S_COUNT];
-    // projection guess: x_j . b (j < GUESS_MAX), b . b, x_new . b_new of the previous solve, sum b
-    double gdot[GUESS_MAX + 3];
+    // projection guess, double-double sums (hi at 2 a, lo at 2 a + 1): a = 0: b . b, 1: sum b, 2 + j: y_j . b,
+    // 2 + GUESS_MAX + j: y_newest . y_j
+    double gdot[2 * (2 * GUESS_MAX + 2)];
 };
 
 }  // namespace tdgl
@@ -356,18 +357,19 @@ struct tdgl_ctx {
     // took it along
     bool xr_active = false, xr_carried = false;
     tdgl::XrArgs xr{};
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 6, 0};
-    // projection guess (popt.extrapolate == 3): window of previous solutions, oldest first;
-    // g_G[i][j] = x_i . b_j in window order (host), the newest diagonal entry arrives with the next
-    // step's status block
-    tdgl::DevBuf<double> g_x[tdgl::GUESS_MAX];
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 0, 0};
+    // projection guess (popt.extrapolate == 3): window of previous solutions x_j and their images
+    // y_j = A x_j (= b_j - r_j with the final residual of the CG recurrence), oldest first;
+    // g_G[i][j] = y_i . y_j in window order, kept on the host as double-double numbers (hi, lo)
+    tdgl::DevBuf<double> g_x[tdgl::GUESS_MAX], g_y[tdgl::GUESS_MAX];
     int g_slot[tdgl::GUESS_MAX] = {0};
     int g_count = 0;
-    bool g_diag_pending = false;
+    bool g_row_pending = false;           // the newest vector's Gram row arrives with the next solve's first status block
     bool mu_first_saved = false;          // mu_prev holds mu^n of a solve that started without a basis
-    double g_G[tdgl::GUESS_MAX][tdgl::GUESS_MAX] = {{0}};
-    double g_rhs[tdgl::GUESS_MAX] = {0};
-    tdgl::DevBuf<double> part_gdot;       // (GUESS_MAX + 3) x NB partials: [x_j . b | b . b | x_new . b_new | sum b]
+    double g_G[tdgl::GUESS_MAX][tdgl::GUESS_MAX][2] = {{{0}}};
+    double g_rhs[tdgl::GUESS_MAX][2] = {{0}};
+    double g_bb[2] = {0, 0};              // (b - mean) . (b - mean) of the right-hand side being solved
+    tdgl::DevBuf<double> part_gdot;       // 2 (2 GUESS_MAX + 2) x NB partials, see StepStatus::gdot
     tdgl::DevBuf<double> d_gdot;          // their sums
     int32_t last_guess_vectors = 0;       // basis size the last guess was formed from
     double last_guess_relres = 0.0;

@@ -203,7 +203,7 @@ SIGNATURES = {
     "tdgl_get_poisson_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     "tdgl_get_guess_stats": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
     "tdgl_get_guess_gram": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
-    "tdgl_host_solve_gram": (C.c_int, [C.c_int32, c_f64p, c_f64p, c_f64p]),
+    "tdgl_host_solve_gram": (C.c_int, [C.c_int32, c_f64p, c_f64p, C.c_double, c_f64p, C.POINTER(C.c_int32)]),
     "tdgl_poisson_set_fused_level": (
         C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p, c_i32p, c_i32p, c_f64p, c_f64p]
     ),

@@ -536,7 +536,7 @@ class TDGLContext:
     def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
                             extrapolate=3, nu_fine=1, fused_restriction=True, precond_fp32=True,
-                            collapse=True, tail_cycles=2, guess_window=6, flexible_cg=False):
+                            collapse=True, tail_cycles=2, guess_window=0, flexible_cg=False):
         kind = {"jacobi": 0, "chebyshev": 1}[smoother] if isinstance(smoother, str) else int(smoother)
         # storage of the V-cycle's operators: False / 0 fp64, 1 fp32, True / 2 fp32 + binary16 on level 0
         from .options import precond_storage_mode
@@ -835,9 +835,9 @@ class TDGLContext:
         return dict(vectors=k.value, initial_relres=r.value)
 
     def guess_gram(self):
-        """Gram matrix ``G_ij = x_i . b_j`` of the projection guess's window (``[k, k]``, oldest first)."""
+        """Gram matrix ``G_ij = y_i . y_j`` (``y = A x``) of the projection guess's window (``[k, k]``, oldest first)."""
         k = C.c_int32(0)
-        G = np.zeros(64)
+        G = np.zeros(256)
         self._chk(self._lib.tdgl_get_guess_gram(self._ctx, C.byref(k), p_f64(G)))
         return G[:k.value * k.value].reshape(k.value, k.value).copy()
 

@@ -516,41 +516,63 @@ def test_collapsed_coarse_operators_are_the_same_cycle():
 
 
 def test_gram_solve_of_the_projection_guess():
-    """tdgl_host_solve_gram: c = pinv(G) rhs with directions below 1e-13 of the largest eigenvalue
-    (of the diagonally scaled matrix) dropped -- against numpy on nearly collinear bases like the
-    ones consecutive mu solutions form."""
+    """tdgl_host_solve_gram: c = argmin ||b - Y c|| from the double-double Gram matrix, L D L^T in
+    double-double arithmetic -- against a QR least-squares solve of the vectors themselves, on nearly
+    collinear bases like the ones consecutive mu solutions form (cond(Y) up to ~1e10: the fp64 normal
+    equations are useless there)."""
     import ctypes as C
+    from fractions import Fraction
 
     from tdgl_amd import _lib
 
     lib = _lib.load()
-    rng = np.random.default_rng(3)
-    n = 400
+    n = 300
     t = np.linspace(0, 1, n)
-    for k in (1, 2, 4, 6, 8):
-        # smooth "trajectory": x_j = f(t_j), consecutive vectors differ by ~1e-2
-        X = np.column_stack([np.sin(3 * t + 0.01 * j) + 0.3 * np.cos(7 * t * (1 + 0.003 * j)) for j in range(k)])
-        A = np.diag(1.0 + rng.random(n))
-        G = X.T @ A @ X
-        b = A @ (np.sin(3 * t + 0.01 * k) + 0.3 * np.cos(7 * t * (1 + 0.003 * k)))
-        rhs = X.T @ b
+
+    def pairs(values):
+        out = np.zeros((len(values), 2))
+        for i, v in enumerate(values):
+            hi = float(v)
+            out[i] = hi, float(v - Fraction(hi))
+        return out
+
+    def exact_dot(u, v):
+        return sum(Fraction(float(a)) * Fraction(float(b)) for a, b in zip(u, v))
+
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    for k, step in ((1, 1e-2), (4, 1e-2), (8, 3e-2), (12, 0.1), (16, 0.2)):
+        # smooth "trajectory": y_j = f(t_j), consecutive vectors differ by ~step
+        traj = lambda j: np.sin(3 * t + step * j) + 0.3 * np.cos(7 * t * (1 + 0.3 * step * j)) + 0.1 * np.exp(-step * j * t)  # noqa: E731
+        Y = np.column_stack([traj(j) for j in range(k)])
+        b = traj(k)
+        G = pairs([exact_dot(Y[:, i], Y[:, j]) for i in range(k) for j in range(k)])
+        g = pairs([exact_dot(Y[:, i], b) for i in range(k)])
         c = np.zeros(k)
-        f = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
-        Gc, rc = np.ascontiguousarray(G), np.ascontiguousarray(rhs)
-        assert lib.tdgl_host_solve_gram(k, f(Gc), f(rc), c.ctypes.data_as(C.POINTER(C.c_double))) == 0
-        # reference: eigen-truncated solve of the scaled matrix
-        s = 1 / np.sqrt(np.diag(G))
-        w, V = np.linalg.eigh(G * s[:, None] * s[None, :])
-        keep = w > 1e-13 * w.max()
-        want = s * (V[:, keep] @ ((V[:, keep].T @ (s * rhs)) / w[keep]))
-        # compare through what matters: the A-norm error of the guess
-        err = lambda cc: np.sqrt((X @ cc - np.linalg.solve(A, b)) @ A @ (X @ cc - np.linalg.solve(A, b)))  # noqa: E731
-        assert err(c) <= 1.05 * err(want) + 1e-12, (k, err(c), err(want))
-        if k >= 4:
-            assert err(c) < 1e-3 * err(np.eye(k)[-1])  # far better than "previous solution"
-    bad = np.zeros((2, 2))
+        used = C.c_int32(0)
+        assert lib.tdgl_host_solve_gram(k, f(G), f(g), 1e-24, f(c), C.byref(used)) == 0
+        want = np.linalg.lstsq(Y, b, rcond=None)[0]
+        res = lambda cc: np.linalg.norm(b - Y @ cc)  # noqa: E731
+        assert min(k, 5) <= used.value <= k
+        # (vectors below the cut carry < 1e-12 of their norm: leaving them out costs at most that)
+        assert res(c) <= 1.5 * res(want) + 3e-11 * np.linalg.norm(b), (k, used.value, res(c), res(want))
+        if k >= 8:  # far beyond what fp64 normal equations resolve (~1e-6 relative on such bases)
+            assert res(c) < 1e-9 * np.linalg.norm(b), (k, res(c))
+            G64 = np.array([[float(np.dot(Y[:, i], Y[:, j])) for j in range(k)] for i in range(k)])
+            c64 = np.linalg.lstsq(G64, Y.T @ b, rcond=1e-13)[0]
+            assert res(c) < 1e-2 * res(c64)
+    # a repeated vector is recognised as dependent and left out; the result is that of the others
+    Y = np.column_stack([traj(0), traj(1), traj(1), traj(2)])
+    b = traj(3)
+    G = pairs([exact_dot(Y[:, i], Y[:, j]) for i in range(4) for j in range(4)])
+    g = pairs([exact_dot(Y[:, i], b) for i in range(4)])
+    c = np.zeros(4)
+    assert lib.tdgl_host_solve_gram(4, f(G), f(g), 1e-24, f(c), C.byref(used)) == 0
+    assert used.value == 3 and c[1] == 0.0  # (the newer copy is kept)
+    want = np.linalg.lstsq(Y[:, [0, 2, 3]], b, rcond=None)[0]
+    assert np.linalg.norm(b - Y @ c) <= 1.5 * np.linalg.norm(b - Y[:, [0, 2, 3]] @ want) + 1e-13
+    bad = np.zeros((2, 2, 2))
     c = np.zeros(2)
-    assert lib.tdgl_host_solve_gram(2, f(bad), f(np.ones(2)), c.ctypes.data_as(C.POINTER(C.c_double))) != 0
+    assert lib.tdgl_host_solve_gram(2, f(bad), f(np.ones((2, 2))), 1e-24, f(c), None) != 0
 
 
 def test_data_handler_streams_the_reference_layout(tmp_path, monkeypatch):
