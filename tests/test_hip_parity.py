@@ -274,10 +274,10 @@ def test_collapsed_coarse_chain_matches_host_restatement(side, max_coarse, mode,
 
 
 def test_projection_guess_gives_the_same_trajectory_in_fewer_iterations():
-    """extrapolate = 3 (A-norm projection of the new solution onto the last six, one K x K solve on
-    the host per step) against the quadratic extrapolation in time: the converged mu is the same
-    to the solver tolerance, the initial residual is an order of magnitude smaller and the solve
-    needs fewer iterations."""
+    """extrapolate = 3 (the smallest-residual combination of the last twelve solutions, double-double dot
+    products and one K x K solve on the host per step) against the quadratic extrapolation in time: the
+    converged mu is the same to the solver tolerance, the initial residual is two orders of magnitude
+    smaller and the solve needs fewer iterations."""
     from tdgl_amd import SolverOptions, TDGLSolver
 
     mesh = synthetic_mesh(120)
@@ -298,9 +298,9 @@ def test_projection_guess_gives_the_same_trajectory_in_fewer_iterations():
     assert max_abs(np.abs(s3["psi"]) ** 2, np.abs(s2["psi"]) ** 2) < 1e-8
     assert max_abs(s3["mu"], s2["mu"]) < 1e-8 * max(1.0, np.abs(s2["mu"]).max())
     assert max_abs(s3["supercurrent"], s2["supercurrent"]) < 1e-8
-    assert g3["vectors"] == 6 and g2["vectors"] == 0
-    assert g3["initial_relres"] < 0.2 * g2["initial_relres"]
-    assert r3["pcg_iters"][50:].mean() < r2["pcg_iters"][50:].mean() - 1.0
+    assert 8 <= g3["vectors"] <= 12 and g2["vectors"] == 0
+    assert g3["initial_relres"] < 0.02 * g2["initial_relres"]
+    assert r3["pcg_iters"][50:].mean() < r2["pcg_iters"][50:].mean() - 2.0
 
 
 def test_fused_restriction_is_the_same_vcycle(small_ctx):
