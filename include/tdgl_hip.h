@@ -532,6 +532,11 @@ int tdgl_normal_current(tdgl_ctx *ctx, const double *mu, double *out);
 /* One application of the AMG V-cycle preconditioner z = M^-1 r on level-0 vectors given in
  * REFERENCE site order (for cross-checks against the host restatement of the cycle). */
 int tdgl_vcycle(tdgl_ctx *ctx, const double *r, double *z);
+/* The dot-product pass of the projection guess (k_multi_dot) on caller-supplied vectors [k, n] and b [n]
+ * (k <= 16): out_pairs[2 a], out_pairs[2 a + 1] = (hi, lo) double-double sums of array a in {0: b . b,
+ * 1: sum b, 2 + j: y_j . b, 18 + j: y_newest . y_j (newest = -1: zeros)}; 2 * 34 doubles. */
+int tdgl_guess_dots(tdgl_ctx *ctx, int32_t k, int64_t n, const double *vectors, const double *b, int32_t newest,
+                    double *out_pairs);
 
 /* ------------------------------------------------------------------ measurement */
 /* Average duration (ms) of `reps` back-to-back launches of one kernel on the context's

@@ -538,13 +538,18 @@ static void launch_ra_laplacian(tdgl_ctx *ctx) {
 // reduce the outcome of the last psi update into d_status (together with the PCG scalars);
 // guess_start: first synchronisation of a solve with the projection guess (sums its partial arrays,
 // sets S_BB / S_TOL2, resets the iteration counters); rr_part: residual partials to sum into S_RR
+// workgroups of the projection guess's dot-product pass (k_multi_dot): two per CU -- its 200+ registers
+// allow no more, and every workgroup ends with a reduction of 2 K + 2 double-double sums.  One process per
+// GPU: the partial arrays are summed over ranks entry by entry, so every rank uses the same count.
+static inline int guess_grid(const tdgl_ctx *ctx) { return std::min(ctx->npart, 512); }
+
 static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double *rr_part = nullptr) {
     const bool psi = ctx->psi_status_pending;
     hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->status_dev, ctx->scal.p,
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
                        ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
-                       guess_start ? ctx->part_gdot.p : (const double *)nullptr, ctx->g_count, (double)ctx->n_global,
+                       guess_start ? ctx->part_gdot.p : (const double *)nullptr, ctx->g_count, guess_grid(ctx), (double)ctx->n_global,
                        ctx->popt.rtol * ctx->popt.rtol, rr_part);
     ctx->psi_status_pending = false;
 }

@@ -275,6 +275,7 @@ SIGNATURES = {
     "tdgl_apply_mu_laplacian": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_apply_mu_boundary_laplacian": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_vcycle": (C.c_int, [_CTX, c_f64p, c_f64p]),
+    "tdgl_guess_dots": (C.c_int, [_CTX, C.c_int32, C.c_int64, c_f64p, c_f64p, C.c_int32, c_f64p]),
     "tdgl_time_kernel": (C.c_int, [_CTX, C.c_int32, C.c_int32, c_f64p]),
     "tdgl_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_profile_read_pcg": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),

@@ -854,6 +854,17 @@ class TDGLContext:
         self._chk(self._lib.tdgl_vcycle(self._ctx, p_f64(r), p_f64(z)))
         return z
 
+    def guess_dots(self, vectors, b, newest=-1):
+        """The projection guess's dot-product pass on ``vectors [k, n]`` and ``b [n]`` (parity tests): dict of
+        ``(hi, lo)`` double-double sums ``bb, sb, yb [k, 2], yy [k, 2]`` (``yy``: ``vectors[newest] . vectors[j]``)."""
+        V = np.ascontiguousarray(vectors, dtype=np.float64)
+        b = f64(b)
+        k, n = V.shape
+        out = np.zeros(2 * 34)
+        self._chk(self._lib.tdgl_guess_dots(self._ctx, k, n, p_f64(V), p_f64(b), int(newest), p_f64(out)))
+        pairs = out.reshape(34, 2)
+        return dict(bb=pairs[0], sb=pairs[1], yb=pairs[2:2 + k].copy(), yy=pairs[18:18 + k].copy())
+
     # -- measurement -----------------------------------------------------------------------------
     def time_kernel(self, kernel: int, reps: int = 20) -> float:
         ms = C.c_double(0)

@@ -303,6 +303,39 @@ def test_projection_guess_gives_the_same_trajectory_in_fewer_iterations():
     assert r3["pcg_iters"][50:].mean() < r2["pcg_iters"][50:].mean() - 2.0
 
 
+@pytest.mark.parametrize("k,n", [(3, 2001), (8, 70000), (12, 5001), (16, 4096)])
+def test_guess_dot_products_are_double_double_exact(small_ctx, k, n):
+    """k_multi_dot (all three compiled windows, odd / even lengths, one and many workgroups): every sum of
+    the pass -- y_j . b, y_newest . y_j, b . b, sum b -- against exact rational arithmetic.  The Gram matrix
+    of the projection guess has a condition number far beyond 1e16; its entries must be good to ~1e-30."""
+    from fractions import Fraction
+
+    ctx, mesh, g = small_ctx
+    rng = np.random.default_rng(k)
+    t = np.linspace(0, 1, n)
+    base = np.sin(5 * t) + rng.standard_normal(n) * 0.3
+    V = np.array([base * (1 + 1e-3 * j) + 1e-6 * j * j * np.cos(9 * t) for j in range(k)])
+    b = base * 1.01 + 1e-7 * rng.standard_normal(n)
+    newest = k - 1
+    got = ctx.guess_dots(V, b, newest)
+
+    def exact(u, v):
+        return sum(Fraction(float(x)) * Fraction(float(y)) for x, y in zip(u, v))
+
+    def check(pair, want, scale):
+        have = Fraction(float(pair[0])) + Fraction(float(pair[1]))
+        assert abs(have - want) <= Fraction(1, 10**27) * scale, (float(have - want), float(scale))
+        assert abs(pair[1]) <= abs(pair[0]) * 2.3e-16  # a normalised pair
+
+    sub = slice(None) if n <= 6000 else slice(0, None, 1)  # (70k: still a few seconds of Fractions)
+    check(got["bb"], exact(b, b), Fraction(float(b @ b)))
+    check(got["sb"], sum(Fraction(float(x)) for x in b), Fraction(float(np.abs(b).sum())))
+    for j in (0, k // 2, k - 1):
+        check(got["yb"][j], exact(V[j][sub], b[sub]), Fraction(float(np.abs(V[j] * b).sum())))
+        check(got["yy"][j], exact(V[j][sub], V[newest][sub]), Fraction(float(np.abs(V[j] * V[newest]).sum())))
+    assert np.all(ctx.guess_dots(V, b, -1)["yy"] == 0.0)
+
+
 def test_fused_restriction_is_the_same_vcycle(small_ctx):
     """R0 (I - c A0 D0^-1) as one operator (tdgl_poisson_set_fused_restriction) vs the level-0
     residual kernel followed by the restriction: same V-cycle, re-associated."""
