@@ -476,6 +476,14 @@ int tdgl_run(tdgl_ctx *ctx, int64_t max_steps, double end_time, double *out_dt,
  * were repeated with a smaller dt (solver.py:475-485), PCG iterations, host synchronisations,
  * nanoseconds the host was blocked in them, nanoseconds inside tdgl_run}. */
 int tdgl_get_step_stats(tdgl_ctx *ctx, int64_t *out6, int32_t reset);
+/* In-loop guard of the direct mu solves (explicit inverses are otherwise checked once, at set-up): once per
+ * batch of queued attempts (one synchronisation per step: every 64th step) the residual of an accepted
+ * step's solve, ||b - A mu|| / ||b|| with the resident level-0 matrix, is measured -- two small launches.
+ * relres_max = the largest value seen, checks = steps checked, fell_back = 1 when a check exceeded the
+ * limit (default 1e-9; the factors deliver 1e-14): the factors were released and every later step uses
+ * AMG-PCG.  tdgl_set_direct_guard changes the limit (tests). */
+int tdgl_get_direct_stats(tdgl_ctx *ctx, double *relres_max, int64_t *checks, int32_t *fell_back);
+int tdgl_set_direct_guard(tdgl_ctx *ctx, double limit);
 
 /* Loop state: stage step index i, Runner.time, Runner.dt (state["dt"] of the next
  * iteration), tentative_dt of the controller. */

@@ -371,6 +371,13 @@ struct tdgl_ctx {
     double g_bb[2] = {0, 0};              // (b - mean) . (b - mean) of the right-hand side being solved
     tdgl::DevBuf<double> part_gdot;       // 2 (2 GUESS_MAX + 2) x NB partials, see StepStatus::gdot
     tdgl::DevBuf<double> d_gdot;          // their sums
+    // in-loop guard of the direct mu solves (run.inc: direct_guard_*): ||b - A mu|| / ||b|| of an accepted step,
+    // measured with the resident level-0 matrix once per run-ahead batch / every DIRECT_GUARD_EVERY classic steps
+    double direct_relres_max = 0.0;
+    int64_t direct_checks = 0;
+    int32_t direct_fell_back = 0;         // a check exceeded direct_guard_limit: the factors were released, AMG-PCG took over
+    int32_t direct_guard_countdown = 0;
+    double direct_guard_limit = 1e-9;
     int32_t last_guess_vectors = 0;       // basis size the last guess was formed from
     double last_guess_relres = 0.0;
     int32_t last_pcg_iters = 0;

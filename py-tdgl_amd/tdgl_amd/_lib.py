@@ -254,6 +254,8 @@ SIGNATURES = {
     "tdgl_get_induced_vector_potential": (C.c_int, [_CTX, c_f64p]),
     "tdgl_induced_vector_potential": (C.c_int, [_CTX, c_f64p, c_f64p]),
     "tdgl_get_step_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.c_int32]),
+    "tdgl_get_direct_stats": (C.c_int, [_CTX, c_f64p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "tdgl_set_direct_guard": (C.c_int, [_CTX, C.c_double]),
     "tdgl_get_loop_state": (
         C.c_int,
         [_CTX, C.POINTER(C.c_int64), c_f64p, c_f64p, c_f64p],

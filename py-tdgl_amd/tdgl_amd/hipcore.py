@@ -69,9 +69,11 @@ class TDGLContext:
     """Owns one ``tdgl_ctx`` (device buffers + stream) for a mesh."""
 
     def __init__(self, mesh, fixed_sites=None, fix_psi=True, u=5.79, gamma=10.0, device_id=0,
-                 reorder="rcm", n_owned=0):
+                 reorder="rcm", n_owned=0, direct_solve=True):
         """``n_owned`` > 0: one-process-per-GPU mode, ``mesh`` is a rank's sub-mesh from
-        `partition.build_local_problem` (owned sites first, then ghosts; no reordering)."""
+        `partition.build_local_problem` (owned sites first, then ghosts; no reordering).
+        ``direct_solve=False``: never use a direct mu solve (plain RCM site order, AMG-PCG whatever the
+        mesh size; ``SolverOptions(sparse_solver="amg_pcg")``)."""
         _lib.require_gpu()
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
@@ -88,10 +90,11 @@ class TDGLContext:
         if n_owned:
             reorder = None
         self._sub_part_ptr = None
+        self.direct_solve = bool(direct_solve)
         if reorder == "rcm":
             with _Stopwatch(self.setup_times, "reorder"):
                 perm = rcm_permutation(em.edges, self.n)
-                if self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
+                if self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
                     # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
                     # then the separator" as the site order (substructure.py); inside a part the sites keep
                     # their reverse Cuthill-McKee order
@@ -175,10 +178,14 @@ class TDGLContext:
         self.set_poisson_options(rtol, max_iter, nu, check_every, edge_currents_every_step,
                                  smoother, cheb_lo, extrapolate, nu_fine)
         limit = self.DENSE_MAX_SITES if dense_max_sites is None else int(dense_max_sites)
-        if self.n_owned == self.n and self._sub_part_ptr is not None and dense_max_sites is None:
-            self.build_substructure(A)
+        if not self.direct_solve:
+            limit = 0
+        # (the factors are held to the tighter of 1e-11 and the iterative solve's tolerance)
+        check = min(1e-11, float(rtol))
+        if self.n_owned == self.n and self._sub_part_ptr is not None and dense_max_sites is None and self.direct_solve:
+            self.build_substructure(A, check_rtol=check)
         elif self.n_owned == self.n and 2 <= self.n <= limit:
-            self.build_dense_inverse(A)
+            self.build_dense_inverse(A, check_rtol=check)
         return h
 
     def build_substructure(self, A=None, check_rtol=1e-11) -> bool:
@@ -233,19 +240,19 @@ class TDGLContext:
         if status != _lib.TDGL_OK:
             return False
         self.setup_times["substructure_device"] = sec.value
-        self.substructure = info
-        self.dense_direct = True
         b = np.random.default_rng(0).standard_normal(self.n)
         _, _, relres = self.poisson_solve(b)
         if not relres <= check_rtol:
-            self.set_dense_inverse(None)
+            self.set_dense_inverse(None)  # (also releases the substructure factors: back to AMG-PCG)
             return False
+        self.substructure = info
+        self.dense_direct = True
         return True
 
     def build_dense_inverse(self, A=None, check_rtol=1e-11) -> bool:
         """Switch the mu solve to the explicit pseudo-inverse (`tdgl_poisson_set_dense_inverse`): built on
-        the device (`tdgl_poisson_build_dense_inverse`); on the host with LAPACK when rocSOLVER cannot be
-        loaded.  The result is checked on a random right-hand side (``||b - A G b|| <= check_rtol ||b||``,
+        the device (`tdgl_poisson_build_dense_inverse`: a blocked symmetric sweep, `csrc/dense.inc`), or on the
+        host with LAPACK when ``TDGL_DENSE_HOST`` is set.  The result is checked on a random right-hand side (``||b - A G b|| <= check_rtol ||b||``,
         the residual the library reports for a one-off solve); a matrix that fails, or whose
         factorisation breaks down (a mesh in several pieces), stays with AMG-PCG.  Returns whether the
         direct solve is on."""
@@ -271,12 +278,12 @@ class TDGLContext:
             if G is None:
                 return False
             self.set_dense_inverse(G)
-        self.dense_direct = True
         b = np.random.default_rng(0).standard_normal(self.n)
         _, _, relres = self.poisson_solve(b)
         if not relres <= check_rtol:
             self.set_dense_inverse(None)
             return False
+        self.dense_direct = True
         return True
 
     def set_dense_inverse(self, G):
@@ -285,6 +292,7 @@ class TDGLContext:
         if G is None:
             self._chk(self._lib.tdgl_poisson_set_dense_inverse(self._ctx, None, 0))
             self.dense_direct = False
+            self.substructure = None
             return
         G = f64(G)
         if G.shape != (self.n, self.n):
@@ -424,6 +432,8 @@ class TDGLContext:
         with _Stopwatch(self.setup_times, "upload"):
             self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(h.levels), p_f64(pinv)))
         self.hierarchy = h
+        self.dense_direct = False  # (tdgl_poisson_set_hierarchy releases the factors of a direct solve)
+        self.substructure = None
         self._hier_epoch = getattr(self, "_hier_epoch", 0) + 1
         self._refresh_fused_restriction()
         self._set_fused_levels(h)
@@ -722,6 +732,21 @@ class TDGLContext:
         self._chk(self._lib.tdgl_get_step_stats(self._ctx, out, int(bool(reset))))
         return dict(steps=out[0], psi_retries=out[1], pcg_iterations=out[2], host_syncs=out[3],
                     host_wait_s=out[4] * 1e-9, run_s=out[5] * 1e-9)
+
+    def direct_stats(self):
+        """In-loop guard of the direct mu solves: ``dict(max, checks, fell_back)`` -- the largest
+        ``||b - A mu|| / ||b||`` measured on accepted steps, the number of steps checked, and whether a check
+        above the limit released the factors (the run continued with AMG-PCG).  Refreshes `dense_direct` /
+        `substructure` accordingly."""
+        r, n, f = C.c_double(0), C.c_int64(0), C.c_int32(0)
+        self._chk(self._lib.tdgl_get_direct_stats(self._ctx, C.byref(r), C.byref(n), C.byref(f)))
+        if f.value:
+            self.dense_direct = False
+            self.substructure = None
+        return dict(max=r.value, checks=n.value, fell_back=bool(f.value))
+
+    def set_direct_guard(self, limit=1e-9):
+        self._chk(self._lib.tdgl_set_direct_guard(self._ctx, float(limit)))
 
     def loop_state(self):
         step, t, rdt, tdt = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)

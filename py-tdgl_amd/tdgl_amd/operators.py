@@ -81,9 +81,12 @@ class MeshOperators:
         """Upload the mesh, build the SELL site graph and set up the AMG hierarchy for the mu
         solve (the counterpart of build_operators + LU factorisation, operators.py:282-308)."""
         o = self._opts
+        from .options import SparseSolver
+
+        forced_iterative = self.sparse_solver in (SparseSolver.AMG_PCG, "amg_pcg", "AMG_PCG")
         self.ctx = TDGLContext(
             self.mesh, fixed_sites=self.fixed_sites, fix_psi=self.fix_psi, u=o["u"],
-            gamma=o["gamma"], device_id=o["device_id"], reorder=o["reorder"],
+            gamma=o["gamma"], device_id=o["device_id"], reorder=o["reorder"], direct_solve=not forced_iterative,
         )
         self.hierarchy = self.ctx.build_poisson(
             rtol=o["pcg_rtol"], max_iter=o["pcg_max_iter"], nu=o["nu"],

@@ -4,10 +4,14 @@
 Differences, all at the backend seam:
 
 * there is exactly one compute path (HIP kernels on MI355X).  ``gpu`` and
-  ``sparse_solver`` are accepted for source compatibility; every value of
-  ``sparse_solver`` selects the AMG-preconditioned CG solve that replaces the reference's
-  sparse LU, and ``gpu`` has no effect (there is no CPU path to fall back to);
-* ``pcg_rtol`` / ``pcg_max_iter`` / ``amg_smoothing_sweeps`` control that solve;
+  ``sparse_solver`` are accepted for source compatibility; ``gpu`` has no effect (there is no CPU
+  path to fall back to).  The reference's solver names (``superlu`` ...) select the library's own
+  choice of mu solve by mesh size: an explicit pseudo-inverse up to 5k sites, a substructured direct
+  solve up to 150k sites (both exact to round-off, checked at set-up against ``min(1e-11, pcg_rtol)``
+  and, in the time loop, by a residual check once per batch of steps: `Solution.stats`), the
+  AMG-preconditioned CG above; ``sparse_solver="amg_pcg"`` forces the iterative solve at every size;
+* ``pcg_rtol`` / ``pcg_max_iter`` / ``amg_smoothing_sweeps`` / ``pcg_precond_fp32`` control the
+  iterative solve and are ignored by the direct ones;
 * results are returned in memory (``tdgl_amd.solution.Solution``); ``output_file`` additionally
   writes them in the reference's HDF5 layout at the end of the run (`tdgl_amd/io.py`, needs
   h5py); ``monitor`` (the reference's live viewer) is accepted and ignored.
@@ -24,7 +28,8 @@ class SolverOptionsError(ValueError):
 
 class SparseSolver(Enum):
     """Names accepted for ``SolverOptions.sparse_solver`` (reference: options.py:10-16) plus
-    the native one.  All of them run the HIP AMG-PCG solve."""
+    the native one.  The reference's names let the library pick the mu solve by mesh size (direct up
+    to 150k sites, AMG-PCG above); ``AMG_PCG`` forces the iterative solve."""
 
     SUPERLU = "superlu"
     UMFPACK = "umfpack"
@@ -60,7 +65,7 @@ class SolverOptions:
     output_file: Union[str, None] = None  # HDF5 file in the reference's layout (needs h5py)
     terminal_psi: Union[float, complex, None] = 0.0  # psi pinned on terminal sites; None = free
     gpu: bool = False  # accepted, no effect: the HIP path is the only path
-    sparse_solver: Union[SparseSolver, str] = SparseSolver.SUPERLU  # any value -> AMG-PCG
+    sparse_solver: Union[SparseSolver, str] = SparseSolver.SUPERLU  # "amg_pcg" forces the iterative mu solve
     pause_on_interrupt: bool = True  # accepted, unused
     save_every: int = 100  # steps between saved snapshots
     progress_interval: int = 0  # accepted, unused

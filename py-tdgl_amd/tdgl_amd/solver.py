@@ -611,6 +611,10 @@ class TDGLSolver:
                 # which mu solve the mesh size selected (hipcore.TDGLContext.build_poisson)
                 mu_solver=("direct (substructured)" if getattr(self.ctx, "substructure", None) else
                            "direct (dense inverse)" if getattr(self.ctx, "dense_direct", False) else "amg_pcg"),
+                # the direct solves' in-loop guard: largest ||b - A mu|| / ||b|| over the checked steps
+                # (one per batch of queued attempts), how many were checked, and whether a check above
+                # 1e-9 sent the run back to AMG-PCG (never observed; the factors deliver 1e-14)
+                **{"mu_residual_" + k: v for k, v in self.ctx.direct_stats().items()},
             ),
         )
         if handler is not None:

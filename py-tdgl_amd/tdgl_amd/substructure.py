@@ -152,9 +152,19 @@ def schur_pinv(schur: np.ndarray) -> np.ndarray:
     return 0.5 * (inv + inv.T) - 1.0 / (s * m)
 
 
-def solve_host(sub: Substructure, b: np.ndarray, spinv: np.ndarray = None) -> np.ndarray:
-    """The device algorithm in NumPy: the zero-mean solution of ``A x = b - mean(b)``."""
+def solve_host(sub: Substructure, b: np.ndarray, spinv: np.ndarray = None, remove_mean: bool = True) -> np.ndarray:
+    """The device algorithm in NumPy: ``pinv(A) b``, the zero-mean solution of ``A x = b - mean(b)``.
+
+    The four launches themselves assume a right-hand side orthogonal to the constants: the pseudo-inverse
+    of the Schur complement projects the SEPARATOR residual only, so for ``sum(b) != 0`` the bare sequence
+    answers ``A x = b - (sum(b) / n_S) e_S`` instead (an error ~25x ``mean(b)`` on a 1.5k-site mesh).  In the
+    time loop ``sum(b) = 0`` holds to round-off (the divergence of an edge field sums to zero site-area
+    weighted, and `validate_terminal_currents` makes the terminal currents add up to zero), and the
+    library's one-off entry point `tdgl_poisson_solve` removes the mean first, as ``remove_mean`` does here;
+    ``remove_mean=False`` reproduces the bare sequence (tests)."""
     nI, P = sub.n_interior, sub.n_parts
+    if remove_mean:
+        b = b - b.mean()
     if spinv is None:
         spinv = schur_pinv(sub.schur)
     y = np.empty(nI)

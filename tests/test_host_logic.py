@@ -1000,6 +1000,32 @@ def test_dense_pseudo_inverse_of_the_poisson_matrix():
     assert dense_pseudo_inverse(two) is None
 
 
+def test_rho_estimate_stays_above_the_spectrum():
+    """`estimate_rho_DinvA` (24 Lanczos steps, Ritz value + residual, Gershgorin cap) is not a guaranteed
+    bound; the Chebyshev smoother diverges above its interval.  Held here: with the build's 5 % margin
+    the estimate covers the true largest eigenvalue (ARPACK) on every level of a graded (600 : 1) and a
+    quasi-uniform mesh, for several start vectors -- and is not wastefully loose."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    from tdgl_amd import amg
+    from tdgl_amd.hipcore import poisson_matrix
+    from test_hip_parity import _graded_ring_mesh
+
+    for mesh in (_graded_ring_mesh(), synthetic_mesh(60)):
+        em = mesh.edge_mesh
+        A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, len(mesh.sites))
+        for L in amg.build_hierarchy(A).levels:
+            if L.A.shape[0] < 60:
+                continue
+            sq = sp.diags(np.sqrt(L.dinv))
+            true = float(spl.eigsh(sq @ L.A @ sq, k=1, which="LA", return_eigenvectors=False, tol=1e-10)[0])
+            for seed in range(6):
+                est = amg.estimate_rho_DinvA(L.A, L.dinv, seed=seed)
+                assert 1.05 * est >= true, (L.A.shape[0], seed, est, true)
+                assert est <= 1.03 * true
+            assert L.rho >= true
+
+
 def test_substructured_solve_on_the_host():
     """Set-up of the substructured direct solve (tdgl_amd/substructure.py): the order (interiors part by part,
     then a separator that covers every cut edge), the block formulas (solve_host = the device algorithm) against
@@ -1027,6 +1053,11 @@ def test_substructured_solve_on_the_host():
     x = solve_host(sub, b)
     want = exact_pinv(A) @ b
     assert np.abs(x - want).max() < 1e-11 * np.abs(want).max() and abs(x.mean()) < 1e-14
+    # a right-hand side with a mean: pinv(A) b all the same -- the mean is removed first; the bare launch
+    # sequence is only valid for sum(b) = 0 (it projects the separator residual only)
+    b1 = b + 1e-3
+    assert np.abs(solve_host(sub, b1) - want).max() < 1e-11 * np.abs(want).max()
+    assert np.abs(solve_host(sub, b1, remove_mean=False) - want).max() > 1e-4 * np.abs(want).max()
     pk = pack_for_device(sub)
     w = down_host(pk, b)
     nI, P = sub.n_interior, sub.n_parts
