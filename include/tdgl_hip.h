@@ -215,12 +215,12 @@ int tdgl_poisson_set_collapsed_tail(tdgl_ctx *ctx, const tdgl_collapsed_tail *ta
  * a hierarchy must have been set (its level-0 matrix measures the residual). */
 int tdgl_poisson_set_dense_inverse(tdgl_ctx *ctx, const double *G, int64_t n);
 /* The same, with G computed on the device from the hierarchy's level-0 matrix (the set-up counterpart of
- * operators.py:305-308 without the host): M = A + (s/n) 1 1^T assembled dense, inverted in place by
- * rocSOLVER's Cholesky routines (dpotrf + dpotri, loaded with dlopen at the first call), packed into the
- * symmetric tile layout with 1 1^T / (s n) removed.  *seconds (may be NULL) = wall time of the call.
- * TDGL_ERR_NOT_READY when rocBLAS / rocSOLVER cannot be loaded (use tdgl_poisson_set_dense_inverse with
- * a host-computed G then), TDGL_ERR_ARG when the factorisation breaks down (a mesh in several pieces
- * has a larger null space: stay with AMG-PCG). */
+ * operators.py:305-308 without the host): M = A + (s/n) 1 1^T assembled as symmetric 128 x 128 tiles and
+ * inverted in place by the library's own blocked symmetric sweep (Gauss-Jordan without pivoting on the
+ * positive definite M, 64-row pivot blocks: k_gj_panel / k_gj_update, csrc/dense.inc -- no rocSOLVER /
+ * rocBLAS is loaded), then 1 1^T / (s n) removed.  *seconds (may be NULL) = wall time of the call.
+ * TDGL_ERR_ARG when a pivot is not positive (a mesh in several pieces has a larger null space: stay with
+ * AMG-PCG, or pass a host-computed G to tdgl_poisson_set_dense_inverse). */
 int tdgl_poisson_build_dense_inverse(tdgl_ctx *ctx, double *seconds);
 
 /* Substructured direct mu solve for mid-size meshes (between the dense inverse above and AMG-PCG): one

@@ -542,14 +542,18 @@ static void launch_ra_laplacian(tdgl_ctx *ctx) {
 // allow no more, and every workgroup ends with a reduction of 2 K + 2 double-double sums.  One process per
 // GPU: the partial arrays are summed over ranks entry by entry, so every rank uses the same count.
 static inline int guess_grid(const tdgl_ctx *ctx) { return std::min(ctx->npart, 512); }
+// one process per GPU with at most G_RANK_STRIDE ranks: the ranks' double-double totals are gathered exactly
+static inline bool guess_rank_totals(const tdgl_ctx *ctx) { return (ctx->world > 1 || ctx->comm != nullptr) && ctx->world <= G_RANK_STRIDE; }
 
 static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double *rr_part = nullptr) {
     const bool psi = ctx->psi_status_pending;
+    const bool rank_totals = guess_rank_totals(ctx);
     hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(BLOCK), 0, ctx->stream, ctx->status_dev, ctx->scal.p,
                        psi ? ctx->psi_dmax_part.p : (const double *)nullptr,
                        psi ? ctx->psi_fail_part.p : (const int32_t *)nullptr, ctx->psi_blocks,
                        ctx->d_gdot.n ? ctx->d_gdot.p : (double *)nullptr,
-                       guess_start ? ctx->part_gdot.p : (const double *)nullptr, ctx->g_count, guess_grid(ctx), (double)ctx->n_global,
+                       guess_start ? (rank_totals ? ctx->part_gdot_rank.p : ctx->part_gdot.p) : (const double *)nullptr, ctx->g_count,
+                       rank_totals ? ctx->world : guess_grid(ctx), rank_totals ? (int)G_RANK_STRIDE : (int)NB, (double)ctx->n_global,
                        ctx->popt.rtol * ctx->popt.rtol, rr_part);
     ctx->psi_status_pending = false;
 }

@@ -357,7 +357,7 @@ struct tdgl_ctx {
     // took it along
     bool xr_active = false, xr_carried = false;
     tdgl::XrArgs xr{};
-    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 0, 0};
+    tdgl_poisson_options popt{3e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 0, 0};
     // projection guess (popt.extrapolate == 3): window of previous solutions x_j and their images
     // y_j = A x_j (= b_j - r_j with the final residual of the CG recurrence), oldest first;
     // g_G[i][j] = y_i . y_j in window order, kept on the host as double-double numbers (hi, lo)
@@ -371,6 +371,7 @@ struct tdgl_ctx {
     double g_bb[2] = {0, 0};              // (b - mean) . (b - mean) of the right-hand side being solved
     tdgl::DevBuf<double> part_gdot;       // 2 (2 GUESS_MAX + 2) x NB partials, see StepStatus::gdot
     tdgl::DevBuf<double> d_gdot;          // their sums
+    tdgl::DevBuf<double> part_gdot_rank;  // one process per GPU: every rank's totals (kernels.inc: k_guess_rank_totals)
     // in-loop guard of the direct mu solves (run.inc: direct_guard_*): ||b - A mu|| / ||b|| of an accepted step,
     // measured with the resident level-0 matrix once per run-ahead batch / every DIRECT_GUARD_EVERY classic steps
     double direct_relres_max = 0.0;
