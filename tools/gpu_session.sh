@@ -3,20 +3,22 @@
 # recipes are gpu_round.sh, gpu_ab.sh and gpu_kernel_ab.sh).  Run from the repo root via gpurun.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-TAG=r04f
-timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_hip_direct.py tests/test_hip_distributed.py -m gpu -q -k "guess or guard or 59k or projection or multi_rank or gram" > $OUT/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $OUT/${TAG}_tests.log
-tail -5 $OUT/${TAG}_tests.log; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_tests.log | head -20
+TAG=r04g
 : > $OUT/AB_${TAG}.jsonl
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --force-distributed --vortex-window off >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_dist1.err
-echo "dist1 rc=$?"
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --vortex-window off >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_single.err
-echo "single rc=$?"
-timeout 900 python bench.py --gpus 4 --transport gloo --steps 5 --warmup 2 --preroll 20 --no-cpu-baseline --config5 off --timeout 800 >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_dry4.err
-echo "dry4 rc=$?"; tail -3 $OUT/${TAG}_dry4.err
+for W in 8 10 12 16; do
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --guess-window $W >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_w$W.err
+  echo "window $W rc=$?"
+done
+for CUT in 1e-18 1e-21 1e-28; do
+  TDGL_GUESS_CUT=$CUT timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_c$CUT.err
+  echo "cut $CUT rc=$?"
+done
 python - <<'PY'
 import json
-for l in open("gpurun_out/AB_r04f.jsonl"):
+for l in open("gpurun_out/AB_r04g.jsonl"):
     try: d = json.loads(l)
     except Exception: continue
-    print(d["config"]["parallelism"][:60], "| head", d["value"], d["pcg"]["mean_iterations"], d["pcg"]["guess"], d.get("host"), d.get("comm_per_step"))
+    def w(x):
+        return None if not x else (x["value"], x["pcg"]["mean_iterations"], (x.get("guess") or {}).get("initial_relres"))
+    print("head", d["value"], d["pcg"]["mean_iterations"], d["pcg"]["guess"], "| vortex", w(d.get("vortex_window")), "| late", w(d.get("late_window")), "| sustained", w(d.get("sustained")))
 PY
