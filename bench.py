@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--preroll", type=int, default=200,
                     help="untimed steps before the warm-up, so that the timed window is the steady state whatever --warmup is")
     ap.add_argument("--workload", default=os.environ.get("TDGL_BENCH_WORKLOAD", "1M"), choices=list(WORKLOADS))
-    ap.add_argument("--rtol", type=float, default=3e-10, help="PCG stopping tolerance (the product default, SolverOptions.pcg_rtol)")
+    ap.add_argument("--rtol", type=float, default=1e-10, help="PCG stopping tolerance (the product default, SolverOptions.pcg_rtol)")
     ap.add_argument("--check-every", type=int, default=0, help="0 = auto (predicted)")
     ap.add_argument("--smoother", default="chebyshev", choices=["chebyshev", "jacobi"])
     ap.add_argument("--nu", type=int, default=2, help="smoother degree on the coarse levels")

@@ -538,10 +538,14 @@ static void launch_ra_laplacian(tdgl_ctx *ctx) {
 // reduce the outcome of the last psi update into d_status (together with the PCG scalars);
 // guess_start: first synchronisation of a solve with the projection guess (sums its partial arrays,
 // sets S_BB / S_TOL2, resets the iteration counters); rr_part: residual partials to sum into S_RR
-// workgroups of the projection guess's dot-product pass (k_multi_dot): two per CU -- its 200+ registers
-// allow no more, and every workgroup ends with a reduction of 2 K + 2 double-double sums.  One process per
-// GPU: the partial arrays are summed over ranks entry by entry, so every rank uses the same count.
-static inline int guess_grid(const tdgl_ctx *ctx) { return std::min(ctx->npart, 512); }
+// workgroups of the projection guess's dot-product pass (k_multi_dot): one per CU -- every workgroup ends with
+// a reduction of 2 K + 2 double-double sums, and the status kernel (ONE workgroup, on the step's critical
+// path) adds that many partials per sum; four waves per CU with 13 16-byte loads per lane in flight keep
+// the stream busy.  (TDGL_GUESS_GRID: A/B switch.)
+static inline int guess_grid(const tdgl_ctx *ctx) {
+    static const char *env = getenv("TDGL_GUESS_GRID");
+    return std::min(ctx->npart, env ? std::max(8, atoi(env) / 8 * 8) : 256);
+}
 // one process per GPU with at most G_RANK_STRIDE ranks: the ranks' double-double totals are gathered exactly
 static inline bool guess_rank_totals(const tdgl_ctx *ctx) { return (ctx->world > 1 || ctx->comm != nullptr) && ctx->world <= G_RANK_STRIDE; }
 

@@ -357,7 +357,7 @@ struct tdgl_ctx {
     // took it along
     bool xr_active = false, xr_carried = false;
     tdgl::XrArgs xr{};
-    tdgl_poisson_options popt{3e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 0, 0};
+    tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 0, 0};
     // projection guess (popt.extrapolate == 3): window of previous solutions x_j and their images
     // y_j = A x_j (= b_j - r_j with the final residual of the CG recurrence), oldest first;
     // g_G[i][j] = y_i . y_j in window order, kept on the host as double-double numbers (hi, lo)

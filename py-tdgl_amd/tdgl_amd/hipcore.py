@@ -162,7 +162,7 @@ class TDGLContext:
     # Schur complement of the separator, ~2 n / sqrt(block) sites, is what grows fastest)
     SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "0"))
 
-    def build_poisson(self, rtol=3e-10, max_iter=500, nu=2, check_every=0,
+    def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
                       cheb_lo=0.1, extrapolate=3, nu_fine=1, dense_max_sites=None) -> Hierarchy:
         """AMG set-up on the host (the counterpart of the reference's LU factorisation,
@@ -543,7 +543,7 @@ class TDGLContext:
             t.V = p_f64(keep[4]) if t.v_cols else None
         self._chk(lib.tdgl_poisson_set_collapsed_tail(ctx, C.byref(t)))
 
-    def set_poisson_options(self, rtol=3e-10, max_iter=500, nu=2, check_every=0,
+    def set_poisson_options(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                             edge_currents_every_step=True, smoother="chebyshev", cheb_lo=0.1,
                             extrapolate=3, nu_fine=1, fused_restriction=True, precond_fp32=True,
                             collapse=True, tail_cycles=2, guess_window=0, flexible_cg=False):

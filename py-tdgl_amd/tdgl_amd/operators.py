@@ -51,7 +51,7 @@ class MeshOperators:
         u: float = 5.79,
         gamma: float = 10.0,
         device_id: int = 0,
-        pcg_rtol: float = 3e-10,
+        pcg_rtol: float = 1e-10,
         pcg_max_iter: int = 500,
         amg_smoothing_sweeps: int = 2,
         edge_currents_every_step: bool = True,

@@ -79,7 +79,7 @@ class SolverOptions:
     screening_step_size: float = 0.1  # screening only
     screening_step_drag: float = 0.5  # screening only
     # --- native Poisson-solve controls (no reference counterpart) ---
-    pcg_rtol: float = 3e-10  # stopping test of the iterative mu solve, ||b - A mu|| <= pcg_rtol ||b|| (chosen from the sweep in profiles/README_r04.md)
+    pcg_rtol: float = 1e-10  # stopping test of the iterative mu solve, ||b - A mu|| <= pcg_rtol ||b|| (sweep: profiles/EXPERIMENTS.md, round 4)
     pcg_max_iter: int = 500
     amg_smoothing_sweeps: int = 2  # Chebyshev degree of the AMG smoother
     # storage of the V-cycle's operators (arithmetic and the CG stay fp64): True = fp32 and, on level 0,
