@@ -164,7 +164,6 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (ctx->h_probe_out) (void)hipHostFree(ctx->h_probe_out);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->ev_status) (void)hipEventDestroy(ctx->ev_status);
     if (ctx->ev_pack) (void)hipEventDestroy(ctx->ev_pack);
     if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
     if (ctx->pcg_graph) (void)hipGraphExecDestroy(ctx->pcg_graph);

@@ -432,8 +432,6 @@ struct tdgl_ctx {
     // ---- measurement -------------------------------------------------------------------
     bool profile = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int psi_step_pending_cur = -1;         // step_once: index of the psi buffer holding the accepted psi^n while a step is in flight (-1: none)
-    hipEvent_t ev_status = nullptr;        // recorded behind the status copy: the host waits for IT when work is queued behind (fetch_scalars)
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
