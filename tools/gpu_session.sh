@@ -3,25 +3,22 @@
 # recipes are gpu_round.sh, gpu_ab.sh and gpu_kernel_ab.sh).  Run from the repo root via gpurun.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-TAG=r04j
-timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_hip_api.py tests/test_hip_errors.py -m gpu -q -x > $OUT/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $OUT/${TAG}_tests.log
-tail -4 $OUT/${TAG}_tests.log; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_tests.log | head -20
+TAG=r04k
 : > $OUT/AB_${TAG}.jsonl
-for V in "" "TDGL_NO_DEFER_CURRENTS=1" "TDGL_GUESS_GRID=512" "" "TDGL_NO_DEFER_CURRENTS=1" "TDGL_GUESS_GRID=512"; do
-  env $V timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --late-steps 2000 > $OUT/ab_tmp.json 2> $OUT/${TAG}_last.err
-  python - "$V" <<'PY' >> $OUT/AB_r04j.jsonl
-import json,sys
-d=json.load(open('gpurun_out/ab_tmp.json'))
-print(json.dumps(dict(variant=sys.argv[1] or "default", head=d["value"], its=d["pcg"]["mean_iterations"], blocked=d["host"]["blocked_frac"], vortex=d["vortex_window"]["value"], vortex_its=d["vortex_window"]["pcg"]["mean_iterations"], sustained=d["sustained"]["value"], sustained_its=d["sustained"]["pcg"]["mean_iterations"], late=d["late_window"]["value"])))
-PY
-  tail -1 $OUT/AB_r04j.jsonl
+timeout 900 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --workload 4M --late-steps 1000 >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_4M.err
+echo "4M rc=$?"
+timeout 1500 python bench.py --gpus 8 --transport gloo --workload 4M --steps 5 --warmup 2 --preroll 20 --no-cpu-baseline --config5 off --timeout 1400 >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_dry8.err
+echo "dry8 rc=$?"; tail -3 $OUT/${TAG}_dry8.err
+for WL in 5k 23k; do
+  timeout 600 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --workload $WL --late-steps 0 >> $OUT/AB_${TAG}.jsonl 2> $OUT/${TAG}_$WL.err
+  echo "$WL rc=$?"
 done
-for WL in 250k strip500k 60k; do
-  timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WL --late-steps 2000 > $OUT/ab_tmp.json 2> $OUT/${TAG}_last.err
-  python - "$WL" <<'PY' >> $OUT/AB_r04j.jsonl
-import json,sys
-d=json.load(open('gpurun_out/ab_tmp.json'))
-print(json.dumps(dict(variant=sys.argv[1], head=d["value"], its=d["pcg"]["mean_iterations"], blocked=d["host"]["blocked_frac"], vortex=(d.get("vortex_window") or {}).get("value"), sustained=(d.get("sustained") or {}).get("value"), late=(d.get("late_window") or {}).get("value"), solver=d["setup_s"].get("mu_solver"))))
+python - <<'PY'
+import json
+for l in open("gpurun_out/AB_r04k.jsonl"):
+    try: d = json.loads(l)
+    except Exception: continue
+    def w(x):
+        return None if not x else (x["value"], x["pcg"]["mean_iterations"])
+    print(d["config"]["workload"][:34], d["config"]["parallelism"][:40], "| head", d["value"], d["pcg"]["mean_iterations"], "| vortex", w(d.get("vortex_window")), "| sustained", w(d.get("sustained")), "| late", w(d.get("late_window")), d.get("comm_per_step"), d["setup_s"].get("total"))
 PY
-  tail -1 $OUT/AB_r04j.jsonl
-done
