@@ -363,6 +363,7 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(StepStatus), hipHostMallocMapped));
     memset(ctx->h_status, 0, sizeof(StepStatus));
     ctx->status_copy = getenv("TDGL_STATUS_MAPPED") == nullptr;
+    ctx->run_ahead_disabled = getenv("TDGL_NO_RUN_AHEAD") != nullptr;
     if (ctx->status_copy) {
         ctx->status_dev = ctx->d_status.p;
     } else {
@@ -547,7 +548,10 @@ static inline int guess_grid(const tdgl_ctx *ctx) {
     return std::min(ctx->npart, env ? std::max(8, atoi(env) / 8 * 8) : 256);
 }
 // one process per GPU with at most G_RANK_STRIDE ranks: the ranks' double-double totals are gathered exactly
-static inline bool guess_rank_totals(const tdgl_ctx *ctx) { return (ctx->world > 1 || ctx->comm != nullptr) && ctx->world <= G_RANK_STRIDE; }
+static inline bool guess_rank_totals(const tdgl_ctx *ctx) {
+    static const bool off = getenv("TDGL_GUESS_NO_GATHER") != nullptr;  // (tests: the path of more than 16 ranks)
+    return (ctx->world > 1 || ctx->comm != nullptr) && ctx->world <= G_RANK_STRIDE && !off;
+}
 
 static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double *rr_part = nullptr) {
     const bool psi = ctx->psi_status_pending;

@@ -322,6 +322,7 @@ struct tdgl_ctx {
     tdgl::StepCtl *h_ctl = nullptr;       // pinned
     tdgl::StepRec *h_rec = nullptr;       // pinned [RA_BATCH_MAX]
     int ra_batch = 4;                     // attempts queued per synchronisation: doubles up to RA_BATCH_MAX
+    bool run_ahead_disabled = false;      // TDGL_NO_RUN_AHEAD, read once when the context is created (tests, A/B runs)
     int ra_retries = 0;                   // failed attempts of the step in progress when the last batch ended ...
     double ra_attempt_dt = 0.0;           // ... and the dt its next attempt takes (the retry state outlives a batch)
     int64_t stat_ra_batches = 0, stat_ra_dead = 0;

@@ -303,6 +303,50 @@ def test_projection_guess_gives_the_same_trajectory_in_fewer_iterations():
     assert r3["pcg_iters"][50:].mean() < r2["pcg_iters"][50:].mean() - 2.0
 
 
+def test_guess_window_sizes_and_a_window_change_on_a_live_context():
+    """Windows 1, 8, 16 (the three compiled forms of the dot-product / combination kernels) against the default
+    12: same trajectory to the solver tolerance, no more iterations with a longer window than with the previous
+    solution alone; and a window shrunk, then grown again, in the middle of a run (the library keeps the newest
+    vectors and their Gram block) continues to the same state."""
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    mesh = synthetic_mesh(120)
+    A = uniform_field_A(mesh, 0.1)
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=1000, pcg_rtol=1e-11)
+
+    def run(windows):
+        solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0)
+        ctx = solver.ctx
+        ctx.set_state(solver.psi_init, solver.mu_init)
+        ctx.begin_stage()
+        dts, its = [], []
+        for w, steps in windows:
+            ctx.set_poisson_options(rtol=1e-11, guess_window=w)
+            res = ctx.run(steps)
+            dts.append(res["dt"])
+            its.append(res["pcg_iters"])
+        out = (np.concatenate(dts), np.concatenate(its), ctx.get_state(), ctx.guess_stats())
+        ctx.close()
+        return out
+
+    ref = run([(12, 150)])
+    assert ref[3]["vectors"] >= 8
+    for w in (1, 8, 16):
+        got = run([(w, 150)])
+        assert got[3]["vectors"] <= w
+        assert np.abs(got[0] - ref[0]).max() <= 1e-8 * ref[0].max()
+        assert max_abs(got[2]["mu"], ref[2]["mu"]) < 1e-8 * max(1.0, np.abs(ref[2]["mu"]).max())
+        assert max_abs(got[2]["supercurrent"], ref[2]["supercurrent"]) < 1e-8
+        if w == 1:
+            assert got[1][50:].mean() > ref[1][50:].mean() + 1.5
+        else:
+            assert got[1][50:].mean() < ref[1][50:].mean() + 1.0
+    live = run([(12, 60), (4, 30), (16, 60)])
+    assert live[3]["vectors"] > 4  # grew again
+    assert np.abs(live[0] - ref[0]).max() <= 1e-8 * ref[0].max()
+    assert max_abs(live[2]["mu"], ref[2]["mu"]) < 1e-8 * max(1.0, np.abs(ref[2]["mu"]).max())
+
+
 @pytest.mark.parametrize("k,n", [(3, 2001), (8, 70000), (12, 5001), (16, 4096)])
 def test_guess_dot_products_are_double_double_exact(small_ctx, k, n):
     """k_multi_dot (all three compiled windows, odd / even lengths, one and many workgroups): every sum of
