@@ -3,6 +3,16 @@
 # recipes are gpu_round.sh, gpu_ab.sh and gpu_kernel_ab.sh).  Run from the repo root via gpurun.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-TAG=r04l
-timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_hip_direct.py tests/test_hip_distributed.py -m gpu -q -k "window_sizes or error_path or more_ranks or run_ahead_loop or guard" > $OUT/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $OUT/${TAG}_tests.log
-tail -5 $OUT/${TAG}_tests.log; grep -E "^(FAILED|ERROR)|^E  " $OUT/${TAG}_tests.log | head -30
+TAG=r04m
+timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $OUT/${TAG}_tests.log
+tail -4 $OUT/${TAG}_tests.log; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_tests.log | head -20
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/${TAG}_smoke.log | cut -c1-400
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/BENCH_${TAG}_1M_driver.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/BENCH_r04m_1M_driver.json"))
+print("head", d["value"], d["pcg"]["mean_iterations"], d["parity_vs_oracle"]["ok"], max(d["parity_vs_oracle"][k] for k in ("dt","abs_sq_psi","mu_zero_mean","J_s","J_n")))
+for k in ("vortex_window","late_window"):
+    x=d[k]; print(k, x["value"], x["pcg"]["mean_iterations"], x["parity_vs_oracle"]["ok"], max(x["parity_vs_oracle"][kk] for kk in ("dt","abs_sq_psi","mu_zero_mean","J_s","J_n")))
+print("sustained", d["sustained"]["value"], d["sustained"]["pcg"])
+PY
