@@ -3,16 +3,18 @@
 # recipes are gpu_round.sh, gpu_ab.sh and gpu_kernel_ab.sh).  Run from the repo root via gpurun.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-TAG=r04m
-timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $OUT/${TAG}_tests.log
-tail -4 $OUT/${TAG}_tests.log; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_tests.log | head -20
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/${TAG}_smoke.log | cut -c1-400
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/BENCH_${TAG}_1M_driver.json 2> $OUT/${TAG}_bench.err; echo "bench rc=$?"
+: > $OUT/SOAK_r04.jsonl
+for JOB in "1M 40000" "250k 100000" "strip500k 60000"; do
+  echo "{\"soak\": \"$JOB\"}" >> $OUT/SOAK_r04.jsonl
+  timeout 900 python tools/soak.py $JOB >> $OUT/SOAK_r04.jsonl 2> $OUT/soak_last.err; echo "$JOB rc=$?"
+done
+echo "{\"soak\": \"60k forced AMG-PCG 150000\"}" >> $OUT/SOAK_r04.jsonl
+TDGL_SUB_MAX_SITES=0 TDGL_DENSE_MAX_SITES=0 timeout 900 python tools/soak.py 60k 150000 >> $OUT/SOAK_r04.jsonl 2> $OUT/soak_last.err; echo "60k rc=$?"
 python - <<'PY'
 import json
-d=json.load(open("gpurun_out/BENCH_r04m_1M_driver.json"))
-print("head", d["value"], d["pcg"]["mean_iterations"], d["parity_vs_oracle"]["ok"], max(d["parity_vs_oracle"][k] for k in ("dt","abs_sq_psi","mu_zero_mean","J_s","J_n")))
-for k in ("vortex_window","late_window"):
-    x=d[k]; print(k, x["value"], x["pcg"]["mean_iterations"], x["parity_vs_oracle"]["ok"], max(x["parity_vs_oracle"][kk] for kk in ("dt","abs_sq_psi","mu_zero_mean","J_s","J_n")))
-print("sustained", d["sustained"]["value"], d["sustained"]["pcg"])
+for l in open("gpurun_out/SOAK_r04.jsonl"):
+    d=json.loads(l)
+    if "soak" in d: print(d); continue
+    last=d
+    if d["steps"] % 20000 == 0 or d["steps"] <= 2500: print(d["steps"], d["wall_s"], d["time"], d["dt_last"], d["pcg_mean"], d["pcg_max"], d["psi_retries"], d["fp64_fallbacks"], d["finite"], d["sites_below_0p1"])
 PY
