@@ -364,12 +364,6 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     memset(ctx->h_status, 0, sizeof(StepStatus));
     ctx->status_copy = getenv("TDGL_STATUS_MAPPED") == nullptr;
     ctx->run_ahead_disabled = getenv("TDGL_NO_RUN_AHEAD") != nullptr;
-    {  // work assignment of the vector-streaming kernels (kernels.inc: stream_range)
-        const int blocked = getenv("TDGL_GRID_STRIDE") ? 0 : 1;
-        HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_blocked_ranges), &blocked, sizeof(int)));
-        const int tiles = getenv("TDGL_BLOCKED_TILES") ? 1 : 0;
-        HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_blocked_tiles), &tiles, sizeof(int)));
-    }
     if (ctx->status_copy) {
         ctx->status_dev = ctx->d_status.p;
     } else {
