@@ -130,10 +130,10 @@ def test_more_ranks_than_the_exact_gather_holds(tmp_path, monkeypatch):
 
 def test_projection_gram_stays_global_through_psi_retries(tmp_path):
     """A psi update that fails abandons the mu solve after its first synchronisation and the step
-    calls the solver again (solver.py:475-485).  The projection guess's dot products are all-reduced
-    in place at that synchronisation; the entry that only the previous converged solve rewrites
-    (x_new . b_new) must be consumed the first time, not summed over the ranks twice.  Checked through
-    the Gram matrix G_ij = x_i . b_j itself -- a global quantity -- of a run with forced retries
+    calls the solver again (solver.py:475-485).  The projection guess's dot products are gathered over
+    the ranks at that synchronisation, and the Gram row of the window's newest vector arrives with them:
+    it must be taken the first time (the second call for the same step computes no row).  Checked through
+    the Gram matrix G_ij = y_i . y_j (y = A x) itself -- a global quantity -- of a run with forced retries
     (dt_init = dt_max = 2, b = 0.8: the reference's own retry fixture settings) on 2 ranks against
     the single-GPU run."""
     kw = dict(dt_init=2.0, dt_max=2.0, b=0.8)
@@ -146,7 +146,7 @@ def test_projection_gram_stays_global_through_psi_retries(tmp_path):
     assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
     assert got["gram"].shape == G.shape and G.shape[0] >= 2
     scale = np.sqrt(np.outer(np.abs(np.diag(G)), np.abs(np.diag(G)))) + 1e-300
-    filled = np.diag(G) != 0  # (the newest diagonal entry travels with the next status block)
+    filled = np.diag(G) != 0  # (every entry is filled: the newest row holds its stand-in y_j . b_new until the next solve)
     assert filled.sum() >= G.shape[0] - 1
     assert np.abs((got["gram"] - G) / scale)[np.ix_(filled, filled)].max() < 1e-6
     assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-8
