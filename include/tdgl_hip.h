@@ -122,8 +122,7 @@ typedef struct {
                              (fused restriction, prolongation, the matrix of the smoothing step)
                              are stored in IEEE binary16 -- same PCG iteration count; falls back
                              to 1 when an entry exceeds binary16's range.  0: everything fp64.  */
-    int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..32; 0 (default) = automatic,
-                             12 .. 24 by the quality of the guess (poisson.inc: guess_window_adapt)       */
+    int32_t guess_window; /* extrapolate = 3: number of previous solutions kept, 1..16 (0 = 12) */
     int32_t flexible_cg;  /* 1: beta = z_{k+1}.(r_{k+1} - r_k) / z_k.r_k (Polak-Ribiere, the "flexible" CG), which
                              tolerates a preconditioner that is not exactly symmetric -- the V-cycle's
                              operators are rounded to fp32 / binary16 one by one.  0 (default): beta =
@@ -303,7 +302,7 @@ int tdgl_get_precond_storage(tdgl_ctx *ctx, int32_t *mode);
 /* Quality of the last solve's initial guess: number of basis vectors it was projected on
  * (extrapolate = 3; 0 = none) and ||b - A x0|| / ||b||. */
 int tdgl_get_guess_stats(tdgl_ctx *ctx, int32_t *vectors, double *initial_relres);
-/* The Gram matrix G_ij = y_i . y_j of the projection guess's window, y_j = A x_j (k <= 32 vectors,
+/* The Gram matrix G_ij = y_i . y_j of the projection guess's window, y_j = A x_j (k <= 16 vectors,
  * row-major [k, k], oldest first, rounded to fp64 from the double-double sums the library keeps; the
  * newest vector's row and column are exact only after the next solve has started -- until then they
  * hold y_j . b_newest): a global quantity, identical on every rank of a decomposed run (tests). */
@@ -542,8 +541,8 @@ int tdgl_normal_current(tdgl_ctx *ctx, const double *mu, double *out);
  * REFERENCE site order (for cross-checks against the host restatement of the cycle). */
 int tdgl_vcycle(tdgl_ctx *ctx, const double *r, double *z);
 /* The dot-product pass of the projection guess (k_multi_dot) on caller-supplied vectors [k, n] and b [n]
- * (k <= 32): out_pairs[2 a], out_pairs[2 a + 1] = (hi, lo) double-double sums of array a in {0: b . b,
- * 1: sum b, 2 + j: y_j . b, 34 + j: y_newest . y_j (newest = -1: zeros)}; 2 * 66 doubles. */
+ * (k <= 16): out_pairs[2 a], out_pairs[2 a + 1] = (hi, lo) double-double sums of array a in {0: b . b,
+ * 1: sum b, 2 + j: y_j . b, 18 + j: y_newest . y_j (newest = -1: zeros)}; 2 * 34 doubles. */
 int tdgl_guess_dots(tdgl_ctx *ctx, int32_t k, int64_t n, const double *vectors, const double *b, int32_t newest,
                     double *out_pairs);
 

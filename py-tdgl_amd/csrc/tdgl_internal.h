@@ -147,7 +147,7 @@ struct XrArgs {
     int npart;  // entries of every partial array in use (tdgl_ctx::npart)
 };
 
-constexpr int GUESS_MAX = 32;  // maximal window of the projection guess (kernels.inc: GK)
+constexpr int GUESS_MAX = 16;  // maximal window of the projection guess (kernels.inc: GK)
 
 // Run-ahead time loop of the direct solves (run.inc: run_ahead): the adaptive-dt controller and the loop's
 // bookkeeping live on the device, so that the host can queue a batch of steps without waiting for each
@@ -365,7 +365,6 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> g_x[tdgl::GUESS_MAX], g_y[tdgl::GUESS_MAX];
     int g_slot[tdgl::GUESS_MAX] = {0};
     int g_count = 0;
-    int g_window_active = 0;              // window in use when the options say 0 = automatic (poisson.inc: guess_window)
     bool g_row_pending = false;           // the newest vector's Gram row arrives with the next solve's first status block
     bool mu_first_saved = false;          // mu_prev holds mu^n of a solve that started without a basis
     double g_G[tdgl::GUESS_MAX][tdgl::GUESS_MAX][2] = {{{0}}};

@@ -862,7 +862,7 @@ class TDGLContext:
     def guess_gram(self):
         """Gram matrix ``G_ij = y_i . y_j`` (``y = A x``) of the projection guess's window (``[k, k]``, oldest first)."""
         k = C.c_int32(0)
-        G = np.zeros(1024)
+        G = np.zeros(256)
         self._chk(self._lib.tdgl_get_guess_gram(self._ctx, C.byref(k), p_f64(G)))
         return G[:k.value * k.value].reshape(k.value, k.value).copy()
 
@@ -885,10 +885,10 @@ class TDGLContext:
         V = np.ascontiguousarray(vectors, dtype=np.float64)
         b = f64(b)
         k, n = V.shape
-        out = np.zeros(2 * 66)
+        out = np.zeros(2 * 34)
         self._chk(self._lib.tdgl_guess_dots(self._ctx, k, n, p_f64(V), p_f64(b), int(newest), p_f64(out)))
-        pairs = out.reshape(66, 2)
-        return dict(bb=pairs[0], sb=pairs[1], yb=pairs[2:2 + k].copy(), yy=pairs[34:34 + k].copy())
+        pairs = out.reshape(34, 2)
+        return dict(bb=pairs[0], sb=pairs[1], yb=pairs[2:2 + k].copy(), yy=pairs[18:18 + k].copy())
 
     # -- measurement -----------------------------------------------------------------------------
     def time_kernel(self, kernel: int, reps: int = 20) -> float:

@@ -345,33 +345,11 @@ def test_guess_window_sizes_and_a_window_change_on_a_live_context():
     assert live[3]["vectors"] > 4  # grew again
     assert np.abs(live[0] - ref[0]).max() <= 1e-8 * ref[0].max()
     assert max_abs(live[2]["mu"], ref[2]["mu"]) < 1e-8 * max(1.0, np.abs(ref[2]["mu"]).max())
-    # guess_window = 0 (the default) adapts between 12 and 24 by the guess's own residual: this smooth run stays at
-    # 12; a run that repeats its psi update every few steps (dt far beyond stability: the retry fixture's settings)
-    # is hard to predict and gets the long window -- beyond what one launch of the passes holds (16)
-    auto = run([(0, 150)])
-    assert auto[3]["vectors"] == 12 and np.abs(auto[0] - ref[0]).max() <= 1e-8 * ref[0].max()
-    rough_opts = SolverOptions(solve_time=1e9, dt_init=2.0, dt_max=2.0, save_every=1000, pcg_rtol=1e-11)
-    outs = {}
-    for w in (0, 12):
-        solver = TDGLSolver.from_dimensionless(mesh, rough_opts, uniform_field_A(mesh, 0.8), 1.0)
-        ctx = solver.ctx
-        ctx.set_poisson_options(rtol=1e-11, guess_window=w)
-        ctx.set_state(solver.psi_init, solver.mu_init)
-        ctx.begin_stage()
-        res = ctx.run(120)
-        outs[w] = (res, ctx.get_state(), ctx.guess_stats(), ctx.step_stats())
-        ctx.close()
-    assert outs[0][3]["psi_retries"] > 10
-    assert 16 < outs[0][2]["vectors"] <= 24 and outs[12][2]["vectors"] <= 12
-    assert np.abs(outs[0][0]["dt"] - outs[12][0]["dt"]).max() <= 1e-8 * outs[12][0]["dt"].max()
-    assert max_abs(outs[0][1]["mu"], outs[12][1]["mu"]) < 1e-7 * max(1.0, np.abs(outs[12][1]["mu"]).max())
-    assert outs[0][0]["pcg_iters"][60:].mean() <= outs[12][0]["pcg_iters"][60:].mean() + 0.2
 
 
-@pytest.mark.parametrize("k,n", [(3, 2001), (8, 70000), (12, 5001), (16, 4096), (24, 3001), (32, 2048)])
+@pytest.mark.parametrize("k,n", [(3, 2001), (8, 70000), (12, 5001), (16, 4096)])
 def test_guess_dot_products_are_double_double_exact(small_ctx, k, n):
-    """k_multi_dot (all three compiled windows, windows longer than one launch holds -- the newest vector then
-    reaches the other launches through its own stream --, odd / even lengths, one and many workgroups): every sum of
+    """k_multi_dot (all three compiled windows, odd / even lengths, one and many workgroups): every sum of
     the pass -- y_j . b, y_newest . y_j, b . b, sum b -- against exact rational arithmetic.  The Gram matrix
     of the projection guess has a condition number far beyond 1e16; its entries must be good to ~1e-30."""
     from fractions import Fraction

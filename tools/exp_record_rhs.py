@@ -34,9 +34,8 @@ rec_b, rec_mu = [], []
 
 def hooked(rhs):
     mu = lu(rhs)
-    if len(dts) >= keep_from:  # (only the tail that is kept stays in memory)
-        rec_b.append(-mesh.areas * rhs)
-        rec_mu.append(mu - mu.mean())
+    rec_b.append(-mesh.areas * rhs)
+    rec_mu.append(mu - mu.mean())
     return mu
 
 
@@ -51,10 +50,9 @@ for k in range(steps):
     dts.append(new_dt)
     dt = new_dt
     t += dt
-    if k % 2000 == 0:
+    if k % 100 == 0:
         print(k, "t", t, "dt", dt, "min|psi|2", (abs(psi) ** 2).min(), time.time() - t0, flush=True)
 sl = slice(keep_from, None)
-k0 = len(rec_b) - (len(dts) - keep_from)  # (retried steps call the solver more than once: keep the accepted tail aligned)
-np.savez(out, b=np.array(rec_b), mu=np.array(rec_mu), dt=np.array(dts[sl]), sites=mesh.sites,
+np.savez(out, b=np.array(rec_b[sl]), mu=np.array(rec_mu[sl]), dt=np.array(dts[sl]), sites=mesh.sites,
          edges=mesh.edge_mesh.edges, w=mesh.edge_mesh.dual_edge_lengths / mesh.edge_mesh.edge_lengths, areas=mesh.areas)
-print("saved", out, len(rec_b), "solves for", len(dts) - keep_from, "steps")
+print("saved", out, len(rec_b) - keep_from, "steps")
