@@ -112,7 +112,6 @@ class TDGLContext:
         self.iperm = np.empty(self.n, dtype=np.int64)
         self.iperm[perm] = np.arange(self.n)
         fixed = i32([] if fixed_sites is None else fixed_sites)
-        self._sites = np.asarray(mesh.sites, dtype=np.float64)
         self._keep = dict(
             edges=edges, areas=f64(mesh.areas), el=f64(em.edge_lengths),
             dl=f64(em.dual_edge_lengths), dirs=f64(em.directions),
@@ -190,21 +189,13 @@ class TDGLContext:
         return h
 
     def _direct_solve_passes(self, check_rtol) -> bool:
-        """The two residual checks a freshly built direct solve must pass: a white-noise right-hand side
-        (``check_rtol``: every mode, the rough ones dominate) and a SMOOTH one, ``L_mu z`` for
-        ``z = cos(pi x / Lx) cos(pi y / Ly)`` -- the kind of right-hand side the time loop produces, and the one
-        an explicit inverse loses digits on first when the mesh is badly conditioned (a mesh graded 600 : 1
-        passes the first check at 1e-11 and leaves 2e-6 .. 6e-6 on the second) -- held to the limit of the
-        in-loop guard, 1e-9."""
+        """Residual check of a freshly built direct solve on a white-noise right-hand side.  (A generic smooth one,
+        L_mu applied to cos(pi x / Lx) cos(pi y / Ly), was tried as a second check in round 4: the factors of the 600 : 1
+        graded mesh pass it at 1e-9 although they leave 2e-6 .. 6e-6 on the right-hand sides the time loop actually
+        produces there -- only measuring THOSE catches it, which is what the in-loop guard does, `direct_stats`.)"""
         b = np.random.default_rng(0).standard_normal(self.n)
         _, _, relres = self.poisson_solve(b)
-        if not relres <= check_rtol:
-            return False
-        xy = self._sites - self._sites.min(axis=0)
-        span = np.maximum(xy.max(axis=0), 1e-300)
-        z = np.cos(np.pi * xy[:, 0] / span[0]) * np.cos(np.pi * xy[:, 1] / span[1])
-        _, _, relres = self.poisson_solve(self.apply_mu_laplacian(z))
-        return bool(relres <= 1e-9)
+        return bool(relres <= check_rtol)
 
     def build_substructure(self, A=None, check_rtol=1e-11) -> bool:
         """Switch the mu solve to the substructured direct solve (`tdgl_poisson_set_substructure`); the
