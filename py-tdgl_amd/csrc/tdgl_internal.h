@@ -145,6 +145,7 @@ struct XrArgs {
     double *scal, *x, *r, *part_rr_out;
     int64_t n;
     int npart;  // entries of every partial array in use (tdgl_ctx::npart)
+    double *part_sx = nullptr;  // (optional) partials of sum x after the update: the zero-mean gauge needs no pass of its own
 };
 
 constexpr int GUESS_MAX = 16;  // maximal window of the projection guess (kernels.inc: GK)
