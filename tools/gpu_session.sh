@@ -3,18 +3,16 @@
 # recipes are gpu_round.sh, gpu_ab.sh and gpu_kernel_ab.sh).  Run from the repo root via gpurun.
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-TAG=r04u
-timeout 2400 python -m pytest tests -m gpu -q > $OUT/${TAG}_tests.log 2>&1; echo "tests rc=$?" >> $OUT/${TAG}_tests.log
-tail -4 $OUT/${TAG}_tests.log; grep -E "^(FAILED|ERROR)" $OUT/${TAG}_tests.log | head -20
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG} -o ${TAG} -- python $OLDPWD/bench.py --steps 100 --warmup 20 --no-cpu-baseline --vortex-window off > $OUT/prof_${TAG}_bench.json 2> $OUT/prof_${TAG}_err.log
-cd $OLDPWD
-DB=$(ls $OUT/prof_${TAG}/*_results.db 2>/dev/null | head -1)
-[ -n "$DB" ] && python tools/rocpd_summary.py $DB "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --vortex-window off" "round 4 ($TAG); MI355X, ROCm 7.2" > $OUT/${TAG}_kernel_stats_1M.txt && grep -E "k_publish_status|k_dot_partial|k_update_xr|k_multi_dot<12>|copyBuffer|total kernel" $OUT/${TAG}_kernel_stats_1M.txt | cut -c1-200
-rm -rf $OUT/prof_${TAG}/*.db 2>/dev/null
-timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/ab_tmp.json 2> $OUT/${TAG}_last.err
-python - <<'PY'
-import json
+: > $OUT/AB_r04w.jsonl
+for WL in 60k 120k 160k; do
+  for MODE in direct amg; do
+    if [ $MODE = amg ]; then export TDGL_SUB_MAX_SITES=0 TDGL_DENSE_MAX_SITES=0; else unset TDGL_SUB_MAX_SITES TDGL_DENSE_MAX_SITES; fi
+    timeout 600 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $WL --late-steps 3000 > $OUT/ab_tmp.json 2> $OUT/r04w_last.err
+    python - "$WL $MODE" <<'PY' >> $OUT/AB_r04w.jsonl
+import json,sys
 d=json.load(open('gpurun_out/ab_tmp.json'))
-print("head", d["value"], d["pcg"]["mean_iterations"], "vortex", d["vortex_window"]["value"], "late", d["late_window"]["value"], "sustained", d["sustained"]["value"])
+print(json.dumps(dict(variant=sys.argv[1], sites=d["config"]["sites"], head=d["value"], its=d["pcg"]["mean_iterations"], vortex=(d.get("vortex_window") or {}).get("value"), sustained=(d.get("sustained") or {}).get("value"), sustained_its=((d.get("sustained") or {}).get("pcg") or {}).get("mean_iterations"), late=(d.get("late_window") or {}).get("value"), solver=d["setup_s"].get("mu_solver"), setup=d["setup_s"].get("total"))))
 PY
+    tail -1 $OUT/AB_r04w.jsonl
+  done
+done
