@@ -12,9 +12,14 @@ controller) on a synthetic square film in a uniform field, fields resident in HB
 JSON line on rank 0.  See DESIGN.md "Measurement" for the byte accounting.
 
 Steady state: whatever ``--warmup`` says, the run first takes ``--preroll`` untimed steps (default
-200) so that the timed window sits where the adaptive time step has opened up and the Poisson
-solve needs its steady ~14 iterations -- the first ~100 steps of the trajectory are cheaper and
-not representative.
+200) so that the timed window sits where the adaptive time step has opened up -- the first ~100
+steps of the trajectory are cheaper and not representative.
+
+Beyond ``value`` (the headline window) a single-GPU run carries on and reports, each with its own
+``parity_vs_oracle`` where the CPU leg runs: ``vortex_window`` (the same number of steps once vortices
+have entered), ``sustained`` (the ``--late-steps`` = 6,000 consecutive steps that follow, timed as a
+whole: what a production run sees) and ``late_window`` (t ~ 440 tau: the adaptive step at dt_max, a
+psi-update retry every few steps).
 """
 
 import argparse
