@@ -1,0 +1,110 @@
+"""ctypes binding of libtdgl_mesh.so (include/tdgl_host_mesh.h): the host-side set-up helpers --
+Delaunay triangulation and the Voronoi dual mesh -- in plain C++ (no HIP, no GPU needed).
+
+Like the HIP library it is built by ``__graft_entry__.build()`` and there is no silent substitute:
+`delaunay` / `dual_mesh` raise if the library is missing.  (SciPy's Qhull remains available by name,
+``meshgen.triangulate(points, backend="qhull")``, and is what the tests compare against.)
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("TDGL_MESH_LIB") or os.path.join(_HERE, "lib", "libtdgl_mesh.so")
+
+OK, ERR_ARG, ERR_DEGENERATE, ERR_SKIPPED, ERR_INDEX = 0, -1, -2, -3, -4
+
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+SIGNATURES = {
+    "tdgl_host_delaunay": (C.c_int, [C.c_int64, _f64p, _i64p, _i64p]),
+    "tdgl_host_is_delaunay": (C.c_int, [C.c_int64, _f64p, C.c_int64, _i64p]),
+    "tdgl_host_dual_mesh": (C.c_int, [C.c_int64, _f64p, C.c_int64, _i64p, _i64p, _i64p, _u8p, _i64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _u8p]),
+}
+
+_lib = None
+
+
+class MeshLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MeshLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = lib
+    return _lib
+
+
+def _xy(points):
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    if pts.ndim != 2 or pts.shape[1] != 2:
+        raise ValueError(f"points must have shape (n, 2), got {pts.shape!r}")
+    return pts
+
+
+def delaunay(points):
+    """``(status, triangles[t, 3] int64)``, counter-clockwise.  status: OK, ERR_SKIPPED (repeated points
+    were left out; the triangulation of the others is returned), ERR_DEGENERATE (all collinear)."""
+    pts = _xy(points)
+    n = len(pts)
+    if n < 3:
+        return ERR_DEGENERATE, np.empty((0, 3), dtype=np.int64)
+    out = np.empty(3 * 2 * n, dtype=np.int64)
+    nt = C.c_int64(0)
+    rc = load().tdgl_host_delaunay(n, pts.ctypes.data_as(_f64p), out.ctypes.data_as(_i64p), C.byref(nt))
+    if rc == ERR_ARG:
+        raise ValueError("tdgl_host_delaunay: non-finite coordinates")
+    return rc, out[: 3 * nt.value].reshape(-1, 3).copy()
+
+
+def is_delaunay(points, triangles) -> bool:
+    pts = _xy(points)
+    tri = np.ascontiguousarray(triangles, dtype=np.int64)
+    rc = load().tdgl_host_is_delaunay(len(pts), pts.ctypes.data_as(_f64p), len(tri), tri.ctypes.data_as(_i64p))
+    if rc < 0:
+        raise ValueError(f"tdgl_host_is_delaunay: status {rc}")
+    return bool(rc)
+
+
+def dual_mesh(points, triangles):
+    """dict(edges[m, 2], is_boundary[m], tri_edge[t, 3], centers[m, 2], directions[m, 2], edge_lengths[m],
+    circumcenters[t, 2], dual_lengths[m], areas[n], suspicious[n]) -- see include/tdgl_host_mesh.h."""
+    pts = _xy(points)
+    tri = np.ascontiguousarray(triangles, dtype=np.int64)
+    n, t = len(pts), len(tri)
+    edges = np.empty((3 * t, 2), dtype=np.int64)
+    is_boundary = np.empty(3 * t, dtype=np.uint8)
+    tri_edge = np.empty((t, 3), dtype=np.int64)
+    cc = np.empty((t, 2))
+    centers = np.empty((3 * t, 2))
+    directions = np.empty((3 * t, 2))
+    edge_lengths = np.empty(3 * t)
+    dual = np.empty(3 * t)
+    areas = np.empty(n)
+    suspicious = np.empty(n, dtype=np.uint8)
+    m = C.c_int64(0)
+    rc = load().tdgl_host_dual_mesh(
+        n, pts.ctypes.data_as(_f64p), t, tri.ctypes.data_as(_i64p), C.byref(m), edges.ctypes.data_as(_i64p),
+        is_boundary.ctypes.data_as(_u8p), tri_edge.ctypes.data_as(_i64p), centers.ctypes.data_as(_f64p),
+        directions.ctypes.data_as(_f64p), edge_lengths.ctypes.data_as(_f64p), cc.ctypes.data_as(_f64p),
+        dual.ctypes.data_as(_f64p), areas.ctypes.data_as(_f64p), suspicious.ctypes.data_as(_u8p))
+    if rc == ERR_INDEX:
+        raise IndexError("a triangle refers to a site that does not exist")
+    if rc != OK:
+        raise ValueError(f"tdgl_host_dual_mesh: status {rc}")
+    m = m.value
+    return dict(edges=edges[:m].copy(), is_boundary=is_boundary[:m].astype(bool), tri_edge=tri_edge,
+                centers=centers[:m].copy(), directions=directions[:m].copy(), edge_lengths=edge_lengths[:m].copy(),
+                circumcenters=cc, dual_lengths=dual[:m].copy(), areas=areas, suspicious=suspicious.astype(bool))

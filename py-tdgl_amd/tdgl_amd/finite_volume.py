@@ -113,6 +113,66 @@ def _reference_hull_areas(areas, which, sites, elements, cc, edges, boundary_edg
         areas[i] = area
 
 
+def _dual_mesh_numpy(sites: np.ndarray, elements: np.ndarray) -> dict:
+    """The Voronoi dual in NumPy -- the construction `tdgl_host_dual_mesh` replaced and is held to, bit for bit
+    (`tests/test_host_logic.py`); `Mesh.from_triangulation(..., backend="numpy")`."""
+    n = len(sites)
+    edges, is_boundary, tri_edge = unique_edges(elements, n)
+    cc = circumcenters(sites, elements)
+    ends = sites[edges]  # (m, 2, 2)
+    centers = ends.mean(axis=1)
+    directions = ends[:, 1] - ends[:, 0]
+    edge_lengths = np.linalg.norm(directions, axis=1)
+
+    # --- dual edge lengths -------------------------------------------------------
+    m = len(edges)
+    flat_edge = tri_edge.ravel()  # (3t,) edge id of each (triangle, local edge)
+    flat_tri = np.repeat(np.arange(len(elements)), 3)
+    order = np.argsort(flat_edge, kind="stable")
+    se, st = flat_edge[order], flat_tri[order]
+    first = np.ones(len(se), dtype=bool)
+    first[1:] = se[1:] != se[:-1]
+    t_a = np.full(m, -1, dtype=np.int64)
+    t_b = np.full(m, -1, dtype=np.int64)
+    t_a[se[first]] = st[first]
+    t_b[se[~first]] = st[~first]
+    interior = t_b >= 0
+    dual = np.empty(m, dtype=float)
+    dual[interior] = np.linalg.norm(cc[t_a[interior]] - cc[t_b[interior]], axis=1)
+    dual[~interior] = np.linalg.norm(cc[t_a[~interior]] - centers[~interior], axis=1)
+
+    # --- Voronoi areas: sum of signed kites (site, edge midpoint, circumcentre) ------
+    # For local edge (p, q) of triangle t with opposite vertex r, the signed height of
+    # the circumcentre above the edge (positive towards r) times |pq|/4 goes to both
+    # p and q.
+    areas = np.zeros(n, dtype=float)
+    suspicious = np.zeros(n, dtype=bool)
+    for k, (ip, iq, ir) in enumerate([(0, 1, 2), (1, 2, 0), (2, 0, 1)]):
+        p = sites[elements[:, ip]]
+        q = sites[elements[:, iq]]
+        r = sites[elements[:, ir]]
+        d = q - p
+        length = np.linalg.norm(d, axis=1)
+        mid = 0.5 * (p + q)
+        # unit normal pointing to the side of r
+        nrm = np.column_stack([-d[:, 1], d[:, 0]]) / length[:, None]
+        side = np.sign(((r - p) * nrm).sum(axis=1))
+        h = ((cc - mid) * nrm).sum(axis=1) * side
+        contrib = 0.25 * length * h
+        # (np.add.at, not bincount + add: the summation order decides the last bit of an area, and the
+        # reference's LU of the singular Neumann matrix -- the oracle's too -- lives on those bits on
+        # tiny meshes, tests/test_hip_parity.py::test_very_small_meshes_match_oracle)
+        np.add.at(areas, elements[:, ip], contrib)
+        np.add.at(areas, elements[:, iq], contrib)
+        # a circumcentre on the far side of its edge: the cell of both end sites needs the
+        # reference's hull-based construction (`_reference_hull_areas`)
+        neg = h < -1e-14 * length
+        suspicious[elements[neg, ip]] = True
+        suspicious[elements[neg, iq]] = True
+    return dict(edges=edges, is_boundary=is_boundary, tri_edge=tri_edge, centers=centers, directions=directions,
+                edge_lengths=edge_lengths, circumcenters=cc, dual_lengths=dual, areas=areas, suspicious=suspicious)
+
+
 class EdgeMesh:
     """Edge-centred quantities of a triangular mesh."""
 
@@ -176,7 +236,7 @@ class Mesh:
         return int(np.argmin(np.linalg.norm(self.sites - np.atleast_2d(xy), axis=1)))
 
     @staticmethod
-    def from_triangulation(sites, elements, create_submesh: bool = True) -> "Mesh":
+    def from_triangulation(sites, elements, create_submesh: bool = True, backend: str = "native") -> "Mesh":
         sites = np.asarray(sites, dtype=float)
         elements = np.asarray(elements, dtype=np.int64)
         if sites.ndim != 2 or sites.shape[1] != 2:
@@ -188,63 +248,22 @@ class Mesh:
                 f"The elements must have shape (m, 3), got {elements.shape!r}."
             )
         n = len(sites)
-        edges, is_boundary, tri_edge = unique_edges(elements, n)
+        if not create_submesh:
+            edges, is_boundary, _ = unique_edges(elements, n)
+            return Mesh(sites, elements, np.unique(edges[is_boundary].ravel()))
+        if backend == "native":  # tdgl_host_dual_mesh (include/tdgl_host_mesh.h): the same numbers, bit for bit, 5x sooner
+            from . import _mesh_lib
+
+            d = _mesh_lib.dual_mesh(sites, elements)
+        elif backend == "numpy":
+            d = _dual_mesh_numpy(sites, elements)
+        else:
+            raise ValueError(f"unknown backend {backend!r}")
+        edges, is_boundary, cc, dual = d["edges"], d["is_boundary"], d["circumcenters"], d["dual_lengths"]
+        areas, suspicious = d["areas"], d["suspicious"]
         boundary_edge_indices = np.flatnonzero(is_boundary)
         boundary_indices = np.unique(edges[is_boundary].ravel())
-        if not create_submesh:
-            return Mesh(sites, elements, boundary_indices)
-
-        cc = circumcenters(sites, elements)
-        ends = sites[edges]  # (m, 2, 2)
-        centers = ends.mean(axis=1)
-        directions = ends[:, 1] - ends[:, 0]
-        edge_lengths = np.linalg.norm(directions, axis=1)
-
-        # --- dual edge lengths -------------------------------------------------------
-        m = len(edges)
-        flat_edge = tri_edge.ravel()  # (3t,) edge id of each (triangle, local edge)
-        flat_tri = np.repeat(np.arange(len(elements)), 3)
-        order = np.argsort(flat_edge, kind="stable")
-        se, st = flat_edge[order], flat_tri[order]
-        first = np.ones(len(se), dtype=bool)
-        first[1:] = se[1:] != se[:-1]
-        t_a = np.full(m, -1, dtype=np.int64)
-        t_b = np.full(m, -1, dtype=np.int64)
-        t_a[se[first]] = st[first]
-        t_b[se[~first]] = st[~first]
-        interior = t_b >= 0
-        dual = np.empty(m, dtype=float)
-        dual[interior] = np.linalg.norm(cc[t_a[interior]] - cc[t_b[interior]], axis=1)
-        dual[~interior] = np.linalg.norm(cc[t_a[~interior]] - centers[~interior], axis=1)
-
-        # --- Voronoi areas: sum of signed kites (site, edge midpoint, circumcentre) ------
-        # For local edge (p, q) of triangle t with opposite vertex r, the signed height of
-        # the circumcentre above the edge (positive towards r) times |pq|/4 goes to both
-        # p and q.
-        areas = np.zeros(n, dtype=float)
-        suspicious = np.zeros(n, dtype=bool)
-        for k, (ip, iq, ir) in enumerate([(0, 1, 2), (1, 2, 0), (2, 0, 1)]):
-            p = sites[elements[:, ip]]
-            q = sites[elements[:, iq]]
-            r = sites[elements[:, ir]]
-            d = q - p
-            length = np.linalg.norm(d, axis=1)
-            mid = 0.5 * (p + q)
-            # unit normal pointing to the side of r
-            nrm = np.column_stack([-d[:, 1], d[:, 0]]) / length[:, None]
-            side = np.sign(((r - p) * nrm).sum(axis=1))
-            h = ((cc - mid) * nrm).sum(axis=1) * side
-            contrib = 0.25 * length * h
-            # (np.add.at, not bincount + add: the summation order decides the last bit of an area, and the
-            # reference's LU of the singular Neumann matrix -- the oracle's too -- lives on those bits on
-            # tiny meshes, tests/test_hip_parity.py::test_very_small_meshes_match_oracle)
-            np.add.at(areas, elements[:, ip], contrib)
-            np.add.at(areas, elements[:, iq], contrib)
-            # a circumcentre on the far side of its edge: the cell of both end sites needs the
-            # reference's hull-based construction (below)
-            neg = h < -1e-14 * length
-            suspicious[elements[neg, ip]] = True
-            suspicious[elements[neg, iq]] = True
+        centers, directions, edge_lengths = d["centers"], d["directions"], d["edge_lengths"]
         if suspicious.any():
             _reference_hull_areas(areas, np.flatnonzero(suspicious), sites, elements, cc, edges,
                                   boundary_edge_indices, boundary_indices)

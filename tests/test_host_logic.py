@@ -11,8 +11,8 @@ from helpers import max_abs, mesh_from_golden, synthetic_mesh, uniform_field_A
 
 
 # ---------------------------------------------------------------- C ABI
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "tdgl_hip.h")).read()
+def _declared_functions(header="tdgl_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tdgl_[a-z0-9_]+)\s*\(", text)))
 
@@ -30,6 +30,14 @@ def test_library_loads_and_exports_every_declared_symbol():
     # the ctypes table covers exactly the header
     assert sorted(_lib.SIGNATURES) == declared
     assert b"gfx950" in lib.tdgl_version()
+    # the host-side mesh helpers (plain C++, their own library)
+    from tdgl_amd import _mesh_lib
+
+    mesh_lib = _mesh_lib.load()
+    declared = _declared_functions("tdgl_host_mesh.h")
+    assert sorted(_mesh_lib.SIGNATURES) == declared and len(declared) == 3
+    for name in declared:
+        assert hasattr(mesh_lib, name), f"{name} declared in include/tdgl_host_mesh.h but not exported"
 
 
 def test_no_silent_cpu_fallback():
@@ -1067,3 +1075,137 @@ def test_substructured_solve_on_the_host():
         r[sub.sep_idx[p]] -= sub.E[p].T @ b[pp[p]:pp[p + 1]]
     gd = np.array([sub.g[pp[p]:pp[p + 1]] @ b[pp[p]:pp[p + 1]] for p in range(P)])
     assert np.abs(w - np.concatenate([y, r, gd])).max() < 1e-12 * np.abs(w).max()
+
+
+# ---------------------------------------------------------------- native mesh set-up (include/tdgl_host_mesh.h)
+def _triangle_set(tri):
+    tri = np.sort(np.asarray(tri), axis=1)
+    return tri[np.lexsort(tri.T[::-1])]
+
+
+def _signed_areas(pts, tri):
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    return 0.5 * ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]))
+
+
+@pytest.mark.parametrize("n", [3, 4, 7, 100, 5000, 60000])
+def test_native_delaunay_finds_qhulls_triangles(n):
+    """Points in general position have ONE Delaunay triangulation: the sweep-hull code and Qhull must agree
+    triangle for triangle (tdgl_amd.meshgen.triangulate replaces scipy.spatial.Delaunay(points).simplices)."""
+    from scipy.spatial import Delaunay
+
+    from tdgl_amd import _mesh_lib
+    from tdgl_amd.meshgen import hex_jitter_points, triangulate
+
+    rng = np.random.default_rng(n)
+    clouds = [rng.random((n, 2)), rng.standard_normal((n, 2)) * [3.0, 0.5] + [10.0, -4.0]]
+    if n == 60000:
+        clouds.append(hex_jitter_points(240, 200))  # the bench recipe: collinear boundary rows
+    for pts in clouds:
+        tri = triangulate(pts)
+        assert tri.dtype == np.int64 and (_signed_areas(pts, tri) > 0).all()  # counter-clockwise
+        assert np.array_equal(_triangle_set(tri), _triangle_set(Delaunay(pts).simplices))
+        assert _mesh_lib.is_delaunay(pts, tri)
+        assert np.array_equal(triangulate(pts, backend="qhull"), Delaunay(pts).simplices)
+    # a thin cloud far from the origin: Qhull's floating-point predicates give up digits there (it returns another,
+    # smaller set of triangles); the exact predicates still deliver a triangulation of ALL points with every edge legal
+    pts = rng.standard_normal((n, 2)) * [1.0, 1e-3] + [1e6, -1e6]
+    tri = triangulate(pts)
+    assert (_signed_areas(pts, tri) > 0).all() and _mesh_lib.is_delaunay(pts, tri) and len(np.unique(tri)) == n
+
+
+def test_native_delaunay_on_degenerate_input():
+    """Cocircular lattices (any diagonal is a valid answer), coordinates far from the origin or tiny, points on a circle,
+    collinear runs: the exact predicates must neither loop nor leave an illegal edge; repeated points are reported, an
+    all-collinear cloud is refused."""
+    from tdgl_amd import _mesh_lib
+    from tdgl_amd.meshgen import hex_jitter_points, triangulate
+
+    grid = np.stack(np.meshgrid(np.arange(40.0), np.arange(25.0)), -1).reshape(-1, 2)
+    ang = np.linspace(0, 2 * np.pi, 300, endpoint=False)
+    cases = {
+        "square lattice": (grid, 39 * 24),
+        "square lattice far from the origin": (grid + 1e9, 39 * 24),  # (Qhull's default options return 2 triangles here)
+        "square lattice, tiny": (grid * 1e-9, 39 * 24 * 1e-18),
+        "square lattice, rotated": (grid @ np.array([[0.6, -0.8], [0.8, 0.6]]), 39 * 24),
+        "hex lattice without jitter": (hex_jitter_points(30, 20, jitter=0.0), 600.0),
+        "circle and its centre": (np.concatenate([[[0.0, 0.0]], np.column_stack([np.cos(ang), np.sin(ang)])]),
+                                  150 * np.sin(2 * np.pi / 300)),
+        "a collinear run and one point": (np.concatenate([np.column_stack([np.arange(50.0), np.zeros(50)]), [[3.3, 7.0]]]), 171.5),
+    }
+    for name, (pts, hull_area) in cases.items():
+        status, tri = _mesh_lib.delaunay(pts)
+        assert status == _mesh_lib.OK, name
+        area = _signed_areas(pts, tri)
+        # (rotated: the rounded boundary rows are no longer exactly collinear, the hull gains slivers whose exactly
+        # positive area this floating-point formula cannot resolve)
+        assert (area > (-1e-12 if "rotated" in name else 0.0)).all(), name
+        assert abs(area.sum() - hull_area) <= 1e-9 * hull_area, name  # covers the hull, no overlap
+        assert len(np.unique(tri)) == len(pts), name
+        # Euler: t = 2 n - 2 - (points on the hull boundary); at least every point is used and the edges are legal
+        assert _mesh_lib.is_delaunay(pts, tri), name
+    # repeated points: reported; `triangulate` hands such a cloud to Qhull as it always did
+    pts = np.concatenate([grid[:100], grid[:5]])
+    status, tri = _mesh_lib.delaunay(pts)
+    assert status == _mesh_lib.ERR_SKIPPED and len(np.unique(tri)) == 100 and _mesh_lib.is_delaunay(pts, tri)
+    assert len(np.unique(triangulate(pts))) == 100
+    status, tri = _mesh_lib.delaunay(np.column_stack([np.arange(50.0), 2 * np.arange(50.0)]))
+    assert status == _mesh_lib.ERR_DEGENERATE
+    with pytest.raises(ValueError, match="collinear"):
+        triangulate(np.column_stack([np.arange(50.0), 2 * np.arange(50.0)]))
+    with pytest.raises(ValueError, match="non-finite"):
+        _mesh_lib.delaunay(np.array([[0.0, 0.0], [1.0, 0.0], [0.0, np.nan]]))
+    # is_delaunay is a real check: flip one diagonal of a jittered cloud
+    pts = np.random.default_rng(0).random((50, 2))
+    tri = triangulate(pts)
+    e = {}
+    for t, (a, b, c) in enumerate(tri):
+        for u, v, w in ((a, b, c), (b, c, a), (c, a, b)):
+            e.setdefault((min(u, v), max(u, v)), []).append((t, w))
+    for (u, v), lst in e.items():
+        if len(lst) == 2:
+            (t0, w0), (t1, w1) = lst
+            quad = pts[[u, w0, v, w1]]  # flipping needs a strictly convex quadrilateral
+            cr = [np.cross(quad[(i + 1) % 4] - quad[i], quad[(i + 2) % 4] - quad[(i + 1) % 4]) for i in range(4)]
+            if all(c > 1e-6 for c in cr) or all(c < -1e-6 for c in cr):
+                bad = tri.copy()
+                bad[t0], bad[t1] = (w0, w1, u), (w1, w0, v)
+                if (_signed_areas(pts, bad[[t0, t1]]) < 0).all():
+                    bad[[t0, t1]] = bad[[t0, t1]][:, ::-1]
+                assert not _mesh_lib.is_delaunay(pts, bad)
+                break
+    else:  # pragma: no cover
+        raise AssertionError("no flippable edge found")
+
+
+def test_native_dual_mesh_is_the_numpy_dual_mesh_bit_for_bit():
+    """tdgl_host_dual_mesh replaces the NumPy construction of edges / circumcentres / dual lengths / cell areas
+    (tdgl/finite_volume/mesh.py:104-151 in the reference) and must not move a bit: the cell areas go into every
+    operator, and their last bits decide tiny meshes (test_hip_parity.py::test_very_small_meshes_match_oracle)."""
+    from tdgl_amd.finite_volume import Mesh
+    from tdgl_amd.meshgen import hex_jitter_points, polygon_mesh, triangulate
+
+    rng = np.random.default_rng(5)
+    film = np.array([[0, 0], [10, 0], [10, 6], [0, 6]], float)
+    hole = np.array([[3, 2], [5, 2], [5, 4], [3, 4]], float)
+    meshes = {
+        "bench recipe": (lambda p: (p, triangulate(p)))(hex_jitter_points(120, 80)),
+        "bench recipe, Qhull's triangle order": (lambda p: (p, triangulate(p, backend="qhull")))(hex_jitter_points(60, 15)),
+        "polygon with a hole": polygon_mesh(film, [hole], 0.4),
+        "random cloud (obtuse boundary triangles: hull-based areas)": (lambda p: (p, triangulate(p)))(rng.random((2000, 2))),
+        "golden mesh": (lambda g: (g["mesh_sites"], g["mesh_elements"]))(load_golden("mesh_small")),
+        "four sites": (np.array([[0.0, 0.0], [1.0, 0.1], [0.9, 1.0], [-0.1, 0.8]]), np.array([[0, 1, 2], [0, 2, 3]])),
+    }
+    for name, (pts, tri) in meshes.items():
+        a = Mesh.from_triangulation(pts, tri)
+        b = Mesh.from_triangulation(pts, tri, backend="numpy")
+        for attr in ("areas", "dual_sites", "boundary_indices"):
+            assert np.array_equal(getattr(a, attr), getattr(b, attr)), (name, attr)
+        for attr in ("edges", "boundary_edge_indices", "edge_lengths", "dual_edge_lengths", "centers", "directions",
+                     "normalized_directions"):
+            assert np.array_equal(getattr(a.edge_mesh, attr), getattr(b.edge_mesh, attr)), (name, attr)
+        assert a.edge_mesh.edges.dtype == b.edge_mesh.edges.dtype and a.areas.dtype == b.areas.dtype
+    with pytest.raises(IndexError):
+        Mesh.from_triangulation(np.zeros((4, 2)) + np.arange(4)[:, None], np.array([[0, 1, 7]]))
+    with pytest.raises(ValueError, match="backend"):
+        Mesh.from_triangulation(*meshes["four sites"], backend="other")

@@ -66,7 +66,17 @@ def test_synthetic_generator_is_the_survey_recipe():
     assert len(mesh.edge_mesh.edges) == 17070
     g = load_golden("traj_zero_field_5k")
     assert np.array_equal(mesh.sites, g["sites"])
-    assert np.array_equal(mesh.elements, g["elements"])
+
+    # the fixture's triangles are Qhull's (the reference recipe calls scipy.spatial.Delaunay); the native
+    # triangulator finds the same triangles in another order (and all counter-clockwise)
+    def as_set(tri):
+        tri = np.sort(np.asarray(tri), axis=1)
+        return tri[np.lexsort(tri.T[::-1])]
+
+    assert np.array_equal(as_set(mesh.elements), as_set(g["elements"]))
+    from tdgl_amd.meshgen import triangulate
+
+    assert np.array_equal(triangulate(mesh.sites, backend="qhull"), g["elements"])
 
 
 # ---------------------------------------------------------------- operators
