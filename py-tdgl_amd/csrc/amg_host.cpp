@@ -1,0 +1,241 @@
+// Host-side AMG set-up loops (include/tdgl_host_amg.h): Lanczos estimate of rho(D^-1 A) and MIS(2) aggregation.
+// Plain C++17 + std::thread.  A team of threads lives for the duration of one call (nothing survives it: safe
+// across fork) and meets at a spinning barrier between the phases; every reduction is over fixed blocks of rows
+// combined in block order, so the results do not depend on the number of threads.
+#include "tdgl_host_amg.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <thread>
+#include <vector>
+
+namespace {
+
+constexpr int64_t BLOCK_ROWS = 8192;
+
+class Team {
+  public:
+    explicit Team(int threads) : n_(std::max(1, threads)) {}
+    int size() const { return n_; }
+    // all members call this; returns when every one has arrived
+    void barrier() {
+        const int gen = generation_.load(std::memory_order_acquire);
+        if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
+            arrived_.store(0, std::memory_order_relaxed);
+            generation_.store(gen + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (generation_.load(std::memory_order_acquire) == gen)
+                if (++spins > 2000) std::this_thread::yield();
+        }
+    }
+    // the rows [begin, end) of member `tid` when `nblocks` blocks are dealt out in contiguous runs
+    static void share(int tid, int members, int64_t nblocks, int64_t &b0, int64_t &b1) {
+        b0 = nblocks * tid / members;
+        b1 = nblocks * (tid + 1) / members;
+    }
+    void run(const std::function<void(int)> &body) {
+        std::vector<std::thread> others;
+        others.reserve((size_t)n_ - 1);
+        for (int t = 1; t < n_; ++t) others.emplace_back(body, t);
+        body(0);
+        for (auto &t : others) t.join();
+    }
+
+  private:
+    int n_;
+    std::atomic<int> arrived_{0};
+    std::atomic<int> generation_{0};
+};
+
+int pick_threads(int requested, int64_t nblocks) {
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    int t = requested > 0 ? requested : std::min(16, hw);
+    t = std::min(t, hw);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(t, nblocks));
+}
+
+}  // namespace
+
+extern "C" int tdgl_host_lanczos(int64_t n, const int32_t *indptr, const int32_t *indices, const double *data, const double *dinv,
+                                 int iters, const double *v0, int threads, double *alpha, double *beta, int *steps,
+                                 double *gershgorin) {
+    if (n < 1 || !indptr || !indices || !data || !dinv || !v0 || !alpha || !beta || !steps || !gershgorin || iters < 1) return -1;
+    const int64_t nblocks = (n + BLOCK_ROWS - 1) / BLOCK_ROWS;
+    Team team(pick_threads(threads, nblocks));
+    std::vector<double> sq((size_t)n), va(v0, v0 + n), vb((size_t)n, 0.0), vc((size_t)n);
+    std::vector<double> part((size_t)nblocks), part_g((size_t)nblocks);
+    double *v = va.data(), *v_prev = vb.data(), *w = vc.data();
+    double b_prev = 0.0;
+    int done = iters;
+    bool stop = false;
+    team.run([&](int tid) {
+        int64_t b0, b1;
+        Team::share(tid, team.size(), nblocks, b0, b1);
+        const int64_t r0 = b0 * BLOCK_ROWS, r1 = std::min(n, b1 * BLOCK_ROWS);
+        // sqrt(dinv), Gershgorin bound
+        for (int64_t b = b0; b < b1; ++b) {
+            double g = 0.0;
+            for (int64_t i = b * BLOCK_ROWS; i < std::min(n, (b + 1) * BLOCK_ROWS); ++i) {
+                sq[(size_t)i] = std::sqrt(dinv[i]);
+                double s = 0.0;
+                for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) s += std::fabs(data[k]);
+                g = std::max(g, s * dinv[i]);
+            }
+            part_g[(size_t)b] = g;
+        }
+        team.barrier();
+        if (tid == 0) {
+            double g = 0.0;
+            for (double x : part_g) g = std::max(g, x);
+            *gershgorin = g;
+        }
+        for (int j = 0; j < iters; ++j) {
+            // w = D^-1/2 A D^-1/2 v - b_prev v_prev;  alpha = w . v
+            for (int64_t b = b0; b < b1; ++b) {
+                double dot = 0.0;
+                for (int64_t i = b * BLOCK_ROWS; i < std::min(n, (b + 1) * BLOCK_ROWS); ++i) {
+                    double y = 0.0;
+                    for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) y += data[k] * (sq[(size_t)indices[k]] * v[indices[k]]);
+                    const double wi = sq[(size_t)i] * y - b_prev * v_prev[i];
+                    w[i] = wi;
+                    dot += wi * v[i];
+                }
+                part[(size_t)b] = dot;
+            }
+            team.barrier();
+            double a = 0.0;  // every member sums the same blocks in the same order
+            for (double x : part) a += x;
+            team.barrier();
+            // w -= alpha v;  beta = |w|
+            for (int64_t b = b0; b < b1; ++b) {
+                double ss = 0.0;
+                for (int64_t i = b * BLOCK_ROWS; i < std::min(n, (b + 1) * BLOCK_ROWS); ++i) {
+                    const double wi = w[i] - a * v[i];
+                    w[i] = wi;
+                    ss += wi * wi;
+                }
+                part[(size_t)b] = ss;
+            }
+            team.barrier();
+            double ss = 0.0;
+            for (double x : part) ss += x;
+            const double bj = std::sqrt(ss);
+            const bool broke = bj <= 1e-12 * std::max(std::fabs(a), 1.0);
+            if (tid == 0) {
+                alpha[j] = a;
+                beta[j] = broke ? 0.0 : bj;
+                if (broke) done = j + 1, stop = true;
+            }
+            if (broke) break;  // (the same decision in every member)
+            // v_prev, v = v, w / beta
+            for (int64_t i = r0; i < r1; ++i) w[i] = w[i] / bj;
+            team.barrier();
+            if (tid == 0) {
+                double *old = v_prev;
+                v_prev = v;
+                v = w;
+                w = old;
+                b_prev = bj;
+            }
+            team.barrier();
+        }
+    });
+    (void)stop;
+    *steps = done;
+    return 0;
+}
+
+extern "C" int tdgl_host_mis2_aggregate(int64_t n, const int32_t *indptr, const int32_t *indices, const double *weight,
+                                        const int64_t *priority, int threads, int64_t *agg, int64_t *n_agg) {
+    if (n < 1 || !indptr || !indices || !weight || !priority || !agg || !n_agg) return -1;
+    const int64_t nblocks = (n + BLOCK_ROWS - 1) / BLOCK_ROWS;
+    Team team(pick_threads(threads, nblocks));
+    std::vector<int8_t> state((size_t)n, 0), root((size_t)n), near1((size_t)n);
+    std::vector<int64_t> p((size_t)n), m1((size_t)n), next_agg((size_t)n);
+    std::vector<int64_t> undecided((size_t)team.size());
+    std::atomic<int> failed{0};
+    int64_t roots = 0;
+    team.run([&](int tid) {
+        int64_t b0, b1;
+        Team::share(tid, team.size(), nblocks, b0, b1);
+        const int64_t r0 = b0 * BLOCK_ROWS, r1 = std::min(n, b1 * BLOCK_ROWS);
+        for (int64_t i = r0; i < r1; ++i) state[(size_t)i] = indptr[i + 1] == indptr[i] ? 1 : 0;  // isolated: its own aggregate
+        team.barrier();
+        int round = 0;
+        for (;; ++round) {
+            int64_t und = 0;
+            for (int64_t i = r0; i < r1; ++i) {
+                const bool u = state[(size_t)i] == 0;
+                p[(size_t)i] = u ? priority[i] : 0;
+                und += u;
+            }
+            undecided[(size_t)tid] = und;
+            team.barrier();
+            int64_t total = 0;
+            for (int64_t x : undecided) total += x;
+            if (total == 0) break;
+            if (round == 200) {
+                failed.store(1);
+                break;
+            }
+            for (int64_t i = r0; i < r1; ++i) {  // largest undecided priority within distance 1
+                int64_t m = p[(size_t)i];
+                for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) m = std::max(m, p[(size_t)indices[k]]);
+                m1[(size_t)i] = m;
+            }
+            team.barrier();
+            for (int64_t i = r0; i < r1; ++i) {  // ... within distance 2: the node itself if it is a new root
+                int64_t m = m1[(size_t)i];
+                for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) m = std::max(m, m1[(size_t)indices[k]]);
+                root[(size_t)i] = state[(size_t)i] == 0 && p[(size_t)i] == m;
+            }
+            team.barrier();
+            for (int64_t i = r0; i < r1; ++i) {
+                if (root[(size_t)i]) state[(size_t)i] = 1;
+                int8_t d = root[(size_t)i];
+                for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) d = std::max(d, root[(size_t)indices[k]]);
+                near1[(size_t)i] = d;
+            }
+            team.barrier();
+            for (int64_t i = r0; i < r1; ++i) {
+                if (state[(size_t)i] != 0) continue;
+                int8_t d = near1[(size_t)i];
+                for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k) d = std::max(d, near1[(size_t)indices[k]]);
+                if (d > 0) state[(size_t)i] = -1;
+            }
+            team.barrier();
+        }
+        team.barrier();
+        if (failed.load()) return;
+        if (tid == 0) {  // roots numbered in ascending node order
+            int64_t c = 0;
+            for (int64_t i = 0; i < n; ++i) agg[i] = state[(size_t)i] == 1 ? c++ : -1;
+            roots = c;
+        }
+        team.barrier();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int64_t i = r0; i < r1; ++i) {
+                int64_t a = agg[i];
+                if (a < 0) {
+                    double best = -1.0;
+                    for (int32_t k = indptr[i]; k < indptr[i + 1]; ++k)
+                        if (agg[indices[k]] >= 0 && weight[k] > best) best = weight[k], a = agg[indices[k]];  // first best in row order
+                }
+                next_agg[(size_t)i] = a;
+            }
+            team.barrier();
+            for (int64_t i = r0; i < r1; ++i) agg[i] = next_agg[(size_t)i];
+            team.barrier();
+        }
+    });
+    if (failed.load()) return -2;
+    for (int64_t i = 0; i < n; ++i)
+        if (agg[i] < 0) agg[i] = roots++;  // (cannot happen for a maximal MIS(2))
+    *n_agg = roots;
+    return 0;
+}

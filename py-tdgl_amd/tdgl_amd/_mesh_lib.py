@@ -1,5 +1,6 @@
-"""ctypes binding of libtdgl_mesh.so (include/tdgl_host_mesh.h): the host-side set-up helpers --
-Delaunay triangulation and the Voronoi dual mesh -- in plain C++ (no HIP, no GPU needed).
+"""ctypes binding of libtdgl_mesh.so (include/tdgl_host_mesh.h, include/tdgl_host_amg.h): the host-side set-up
+helpers -- Delaunay triangulation, the Voronoi dual mesh, and the two loops of the AMG set-up (Lanczos estimate of
+rho(D^-1 A), MIS(2) aggregation) -- in plain C++ (no HIP, no GPU needed).
 
 Like the HIP library it is built by ``__graft_entry__.build()`` and there is no silent substitute:
 `delaunay` / `dual_mesh` raise if the library is missing.  (SciPy's Qhull remains available by name,
@@ -17,12 +18,17 @@ LIB_PATH = os.environ.get("TDGL_MESH_LIB") or os.path.join(_HERE, "lib", "libtdg
 OK, ERR_ARG, ERR_DEGENERATE, ERR_SKIPPED, ERR_INDEX = 0, -1, -2, -3, -4
 
 _i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
 
 SIGNATURES = {
     "tdgl_host_delaunay": (C.c_int, [C.c_int64, _f64p, _i64p, _i64p]),
     "tdgl_host_is_delaunay": (C.c_int, [C.c_int64, _f64p, C.c_int64, _i64p]),
+    # include/tdgl_host_amg.h
+    "tdgl_host_lanczos": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int, _f64p, C.c_int, _f64p, _f64p,
+                                    C.POINTER(C.c_int), _f64p]),
+    "tdgl_host_mis2_aggregate": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _i64p, C.c_int, _i64p, _i64p]),
     "tdgl_host_dual_mesh": (C.c_int, [C.c_int64, _f64p, C.c_int64, _i64p, _i64p, _i64p, _u8p, _i64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _u8p]),
 }
 
@@ -108,3 +114,48 @@ def dual_mesh(points, triangles):
     return dict(edges=edges[:m].copy(), is_boundary=is_boundary[:m].astype(bool), tri_edge=tri_edge,
                 centers=centers[:m].copy(), directions=directions[:m].copy(), edge_lengths=edge_lengths[:m].copy(),
                 circumcenters=cc, dual_lengths=dual[:m].copy(), areas=areas, suspicious=suspicious.astype(bool))
+
+
+def _csr32(A):
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    return indptr, indices
+
+
+def lanczos(A, dinv, v0, iters, threads=0):
+    """``(alpha[steps], beta[steps], gershgorin)`` of `tdgl_host_lanczos` for the CSR matrix ``A``
+    (include/tdgl_host_amg.h)."""
+    n = A.shape[0]
+    if A.nnz >= 2**31:
+        raise ValueError("matrix too large for 32-bit indices")
+    indptr, indices = _csr32(A)
+    data = np.ascontiguousarray(A.data, dtype=np.float64)
+    dinv = np.ascontiguousarray(dinv, dtype=np.float64)
+    v0 = np.ascontiguousarray(v0, dtype=np.float64)
+    alpha, beta = np.zeros(iters), np.zeros(iters)
+    steps, gersh = C.c_int(0), C.c_double(0.0)
+    rc = load().tdgl_host_lanczos(n, indptr.ctypes.data_as(_i32p), indices.ctypes.data_as(_i32p), data.ctypes.data_as(_f64p),
+                                  dinv.ctypes.data_as(_f64p), int(iters), v0.ctypes.data_as(_f64p), int(threads),
+                                  alpha.ctypes.data_as(_f64p), beta.ctypes.data_as(_f64p), C.byref(steps), C.byref(gersh))
+    if rc != 0:
+        raise ValueError(f"tdgl_host_lanczos: status {rc}")
+    return alpha[: steps.value], beta[: steps.value], gersh.value
+
+
+def mis2_aggregate(S, priority, threads=0):
+    """``(agg[n] int64, n_agg)`` of `tdgl_host_mis2_aggregate` for the strength graph ``S`` (CSR, no diagonal)."""
+    n = S.shape[0]
+    if S.nnz >= 2**31:
+        raise ValueError("graph too large for 32-bit indices")
+    indptr, indices = _csr32(S)
+    w = np.ascontiguousarray(np.abs(S.data), dtype=np.float64)
+    prio = np.ascontiguousarray(priority, dtype=np.int64)
+    agg = np.empty(n, dtype=np.int64)
+    n_agg = C.c_int64(0)
+    rc = load().tdgl_host_mis2_aggregate(n, indptr.ctypes.data_as(_i32p), indices.ctypes.data_as(_i32p), w.ctypes.data_as(_f64p),
+                                         prio.ctypes.data_as(_i64p), int(threads), agg.ctypes.data_as(_i64p), C.byref(n_agg))
+    if rc == -2:
+        raise RuntimeError("MIS(2) did not terminate")
+    if rc != 0:
+        raise ValueError(f"tdgl_host_mis2_aggregate: status {rc}")
+    return agg, int(n_agg.value)

@@ -50,11 +50,19 @@ def _hash_priority(n, level_seed):
     return (rng.permutation(n) + 1).astype(np.int64)
 
 
-def mis2_aggregate(S: sp.csr_matrix, seed: int = 0):
+def mis2_aggregate(S: sp.csr_matrix, seed: int = 0, backend: str = "native"):
     """Aggregate the nodes of the symmetric strength graph ``S`` (CSR, no diagonal).
 
-    Returns ``(agg[n] int64, n_agg)``.
+    Returns ``(agg[n] int64, n_agg)``.  ``backend="native"``: `tdgl_host_mis2_aggregate` (include/tdgl_host_amg.h,
+    threaded C++), ``"numpy"``: the construction it replaced -- the same aggregates, node for node
+    (`tests/test_host_logic.py`).
     """
+    if backend == "native":
+        from . import _mesh_lib
+
+        return _mesh_lib.mis2_aggregate(S, _hash_priority(S.shape[0], seed))
+    if backend != "numpy":
+        raise ValueError(f"unknown backend {backend!r}")
     n = S.shape[0]
     indptr, indices = S.indptr, S.indices
     prio = _hash_priority(n, seed)
@@ -108,7 +116,7 @@ def mis2_aggregate(S: sp.csr_matrix, seed: int = 0):
     return agg, n_agg
 
 
-def estimate_rho_DinvA(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 24, seed: int = 0):
+def estimate_rho_DinvA(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 24, seed: int = 0, backend: str = "native"):
     """Estimate (from above, in practice) of the largest eigenvalue of D^-1 A: ``iters`` Lanczos steps
     on the symmetrised operator D^-1/2 A D^-1/2, largest Ritz value plus the norm of its residual,
     capped by the Gershgorin bound.  Not a guaranteed bound: theta + r only guarantees an eigenvalue
@@ -121,18 +129,34 @@ def estimate_rho_DinvA(A: sp.csr_matrix, dinv: np.ndarray, iters: int = 24, seed
     (which converges from below, slowly) is not safe; a fixed, small number of Lanczos steps with the
     residual added is (the classical recipe of AMG codes), and costs ``iters`` matrix-vector products
     instead of the ~200 a converged ARPACK run takes (the largest single item of the set-up at 1M
-    sites)."""
+    sites).
+
+    ``backend="native"`` runs the Lanczos recurrence in `tdgl_host_lanczos` (include/tdgl_host_amg.h; threaded, dot
+    products summed block-wise in a fixed order: the same value on any number of threads), ``"numpy"`` the loop it
+    replaced (BLAS dot products: the two agree to round-off, `tests/test_host_logic.py`)."""
     n = A.shape[0]
     rng = np.random.default_rng(seed)
     sq = np.sqrt(dinv)
-    # Gershgorin: never exceeded, and tight (= 2) for the fine-level M-matrix
-    gersh = float((abs(A) @ np.ones(n) * dinv).max())
     if n < 50:
+        gersh = float((abs(A) @ np.ones(n) * dinv).max())
         S = (A.toarray() * sq[:, None]) * sq[None, :]
         return min(gersh, float(np.linalg.eigvalsh(S)[-1]))
     m = int(min(iters, n - 1))
     v = rng.standard_normal(n)
     v /= np.linalg.norm(v)
+    if backend == "native":
+        from . import _mesh_lib
+
+        A = sp.csr_matrix(A)
+        alpha, beta, gersh = _mesh_lib.lanczos(A, dinv, v, m)
+        steps = len(alpha)
+        T = np.diag(alpha) + np.diag(beta[:steps - 1], 1) + np.diag(beta[:steps - 1], -1)
+        theta, Y = np.linalg.eigh(T)
+        return min(gersh, float(theta[-1] + abs(beta[steps - 1] * Y[-1, -1])))
+    if backend != "numpy":
+        raise ValueError(f"unknown backend {backend!r}")
+    # Gershgorin: never exceeded, and tight (= 2) for the fine-level M-matrix
+    gersh = float((abs(A) @ np.ones(n) * dinv).max())
     v_prev = np.zeros(n)
     alpha, beta = np.zeros(m), np.zeros(m)
     b_prev = 0.0

@@ -34,10 +34,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     from tdgl_amd import _mesh_lib
 
     mesh_lib = _mesh_lib.load()
-    declared = _declared_functions("tdgl_host_mesh.h")
-    assert sorted(_mesh_lib.SIGNATURES) == declared and len(declared) == 3
+    declared = sorted(_declared_functions("tdgl_host_mesh.h") + _declared_functions("tdgl_host_amg.h"))
+    assert sorted(_mesh_lib.SIGNATURES) == declared and len(declared) == 5
     for name in declared:
-        assert hasattr(mesh_lib, name), f"{name} declared in include/tdgl_host_mesh.h but not exported"
+        assert hasattr(mesh_lib, name), f"{name} declared in include/tdgl_host_mesh.h / tdgl_host_amg.h but not exported"
 
 
 def test_no_silent_cpu_fallback():
@@ -1166,7 +1166,8 @@ def test_native_delaunay_on_degenerate_input():
         if len(lst) == 2:
             (t0, w0), (t1, w1) = lst
             quad = pts[[u, w0, v, w1]]  # flipping needs a strictly convex quadrilateral
-            cr = [np.cross(quad[(i + 1) % 4] - quad[i], quad[(i + 2) % 4] - quad[(i + 1) % 4]) for i in range(4)]
+            ed = [quad[(i + 1) % 4] - quad[i] for i in range(4)]
+            cr = [ed[i][0] * ed[(i + 1) % 4][1] - ed[i][1] * ed[(i + 1) % 4][0] for i in range(4)]
             if all(c > 1e-6 for c in cr) or all(c < -1e-6 for c in cr):
                 bad = tri.copy()
                 bad[t0], bad[t1] = (w0, w1, u), (w1, w0, v)
@@ -1209,3 +1210,76 @@ def test_native_dual_mesh_is_the_numpy_dual_mesh_bit_for_bit():
         Mesh.from_triangulation(np.zeros((4, 2)) + np.arange(4)[:, None], np.array([[0, 1, 7]]))
     with pytest.raises(ValueError, match="backend"):
         Mesh.from_triangulation(*meshes["four sites"], backend="other")
+
+
+# ---------------------------------------------------------------- native AMG set-up loops (include/tdgl_host_amg.h)
+def _poisson_and_strength(side):
+    import scipy.sparse as sp
+
+    from tdgl_amd.hipcore import poisson_matrix
+
+    mesh = synthetic_mesh(side)
+    em = mesh.edge_mesh
+    n = len(mesh.sites)
+    A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, n, np.arange(n)).tocsr()
+    C = A.tocoo()
+    off = (C.row != C.col) & (C.data != 0)
+    S = sp.csr_matrix((C.data[off], (C.row[off], C.col[off])), shape=A.shape)
+    S.sort_indices()
+    return A, S
+
+
+def test_native_mis2_aggregation_is_the_numpy_aggregation_node_for_node():
+    import scipy.sparse as sp
+
+    from tdgl_amd import _mesh_lib, amg
+
+    for side in (12, 70, 160):
+        A, S = _poisson_and_strength(side)
+        for seed in (0, 1):
+            a0, n0 = amg.mis2_aggregate(S, seed, backend="numpy")
+            a1, n1 = amg.mis2_aggregate(S, seed)
+            assert n0 == n1 and np.array_equal(a0, a1) and a1.dtype == np.int64
+        # any number of threads
+        prio = amg._hash_priority(S.shape[0], 0)
+        for threads in (1, 3, 8):
+            a2, n2 = _mesh_lib.mis2_aggregate(S, prio, threads=threads)
+            assert np.array_equal(a2, amg.mis2_aggregate(S, 0, backend="numpy")[0])
+    # isolated nodes are their own aggregates; a second-level graph (weights of both signs)
+    S = sp.csr_matrix(np.array([[0, 2.0, 0, 0], [2.0, 0, -1.0, 0], [0, -1.0, 0, 0], [0, 0, 0, 0]]))
+    a0, n0 = amg.mis2_aggregate(S, 0, backend="numpy")
+    a1, n1 = amg.mis2_aggregate(S, 0)
+    assert n0 == n1 == 2 and np.array_equal(a0, a1)
+    h = amg.build_hierarchy(_poisson_and_strength(70)[0])
+    A1 = h.levels[1].A.tocoo()
+    off = A1.row != A1.col
+    S1 = sp.csr_matrix((A1.data[off], (A1.row[off], A1.col[off])), shape=A1.shape)
+    S1.sort_indices()
+    assert np.array_equal(amg.mis2_aggregate(S1, 1)[0], amg.mis2_aggregate(S1, 1, backend="numpy")[0])
+
+
+def test_native_lanczos_matches_the_numpy_recurrence_and_does_not_depend_on_threads():
+    from tdgl_amd import _mesh_lib, amg
+
+    for side in (20, 70, 160):
+        A, _ = _poisson_and_strength(side)
+        dinv = 1.0 / A.diagonal()
+        for seed in (0, 3):
+            r0 = amg.estimate_rho_DinvA(A, dinv, seed=seed, backend="numpy")
+            r1 = amg.estimate_rho_DinvA(A, dinv, seed=seed)
+            assert abs(r1 - r0) <= 1e-12 * r0
+        v = np.random.default_rng(0).standard_normal(A.shape[0])
+        v /= np.linalg.norm(v)
+        ref = _mesh_lib.lanczos(A, dinv, v, 24, threads=1)
+        for threads in (2, 5, 8):
+            got = _mesh_lib.lanczos(A, dinv, v, 24, threads=threads)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+        assert ref[2] == float((abs(A) @ np.ones(A.shape[0]) * dinv).max())
+    # an invariant subspace ends the recurrence: the two-site Laplacian from an eigenvector
+    import scipy.sparse as sp
+
+    n = 64
+    B = sp.diags([np.full(n, 2.0)], [0]).tocsr()
+    v = np.ones(n) / np.sqrt(n)
+    alpha, beta, g = _mesh_lib.lanczos(B, np.full(n, 0.5), v, 10)
+    assert len(alpha) == 1 and beta[0] == 0.0 and abs(alpha[0] - 1.0) < 1e-15 and g == 1.0
