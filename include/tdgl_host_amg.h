@@ -34,6 +34,17 @@ int tdgl_host_lanczos(int64_t n, const int32_t *indptr, const int32_t *indices, 
 int tdgl_host_mis2_aggregate(int64_t n, const int32_t *indptr, const int32_t *indices, const double *weight,
                              const int64_t *priority, int threads, int64_t *agg, int64_t *n_agg);
 
+/* C = A B for CSR matrices with 32-bit indices (A: rows x inner, B: inner x cols): the Galerkin products and the
+ * pre-multiplied operators of the AMG set-up, which SciPy computes on one thread.  Row blocks are dealt to threads;
+ * every entry is accumulated in the order (entries of A's row) x (entries of B's row), exact zeros are not stored
+ * and the columns of a row come out ascending, so the result does not depend on the number of threads.
+ * `tdgl_host_spgemm` returns a handle (NULL on bad arguments) and the number of stored entries in *nnz;
+ * `tdgl_host_spgemm_take` copies the result into indptr[rows + 1], indices[nnz], data[nnz] (a NULL indptr discards
+ * it) and releases the handle. */
+void *tdgl_host_spgemm(int64_t rows, int64_t cols, const int32_t *a_indptr, const int32_t *a_indices, const double *a_data,
+                       const int32_t *b_indptr, const int32_t *b_indices, const double *b_data, int threads, int64_t *nnz);
+int tdgl_host_spgemm_take(void *handle, int64_t *indptr, int32_t *indices, double *data);
+
 #ifdef __cplusplus
 }
 #endif

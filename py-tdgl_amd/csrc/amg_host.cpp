@@ -239,3 +239,87 @@ extern "C" int tdgl_host_mis2_aggregate(int64_t n, const int32_t *indptr, const 
     *n_agg = roots;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// C = A B for CSR matrices (Gustavson, row blocks dealt to threads, one dense accumulator per thread).  Every entry
+// is accumulated in the order (entries of A's row) x (entries of B's row), exact zeros are not stored, the columns
+// of a row come out ascending: the result does not depend on the number of threads.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Product {
+    int64_t rows = 0;
+    std::vector<int64_t> row_nnz;               // per row
+    std::vector<std::vector<int32_t>> indices;  // per thread, rows in order
+    std::vector<std::vector<double>> data;
+    std::vector<int64_t> first_row;             // per thread (+ end)
+};
+}  // namespace
+
+extern "C" void *tdgl_host_spgemm(int64_t rows, int64_t cols, const int32_t *a_indptr, const int32_t *a_indices, const double *a_data,
+                                  const int32_t *b_indptr, const int32_t *b_indices, const double *b_data, int threads, int64_t *nnz) {
+    if (rows < 0 || cols < 1 || !a_indptr || !b_indptr || !nnz) return nullptr;
+    if ((a_indptr[rows] > 0 && (!a_indices || !a_data)) || cols > (int64_t)2147483647) return nullptr;
+    // accumulators: 12 bytes per column and thread, at most ~512 MB in all
+    int t = pick_threads(threads, std::max<int64_t>(1, rows / 64));
+    t = (int)std::max<int64_t>(1, std::min<int64_t>(t, ((int64_t)512 << 20) / (12 * cols)));
+    Team team(t);
+    auto *out = new Product;
+    out->rows = rows;
+    out->row_nnz.assign((size_t)rows, 0);
+    out->indices.resize((size_t)t);
+    out->data.resize((size_t)t);
+    out->first_row.resize((size_t)t + 1);
+    for (int k = 0; k <= t; ++k) out->first_row[(size_t)k] = rows * k / t;
+    team.run([&](int tid) {
+        std::vector<double> sums((size_t)cols, 0.0);
+        std::vector<uint8_t> seen((size_t)cols, 0);
+        std::vector<int32_t> touched;
+        auto &idx = out->indices[(size_t)tid];
+        auto &val = out->data[(size_t)tid];
+        for (int64_t i = out->first_row[(size_t)tid]; i < out->first_row[(size_t)tid + 1]; ++i) {
+            touched.clear();
+            for (int32_t jj = a_indptr[i]; jj < a_indptr[i + 1]; ++jj) {
+                const int32_t j = a_indices[jj];
+                const double v = a_data[jj];
+                for (int32_t kk = b_indptr[j]; kk < b_indptr[j + 1]; ++kk) {
+                    const int32_t k = b_indices[kk];
+                    if (!seen[(size_t)k]) seen[(size_t)k] = 1, touched.push_back(k);
+                    sums[(size_t)k] += v * b_data[kk];
+                }
+            }
+            std::sort(touched.begin(), touched.end());
+            int64_t count = 0;
+            for (int32_t k : touched) {
+                if (sums[(size_t)k] != 0.0) {
+                    idx.push_back(k);
+                    val.push_back(sums[(size_t)k]);
+                    ++count;
+                }
+                sums[(size_t)k] = 0.0;
+                seen[(size_t)k] = 0;
+            }
+            out->row_nnz[(size_t)i] = count;
+        }
+    });
+    int64_t total = 0;
+    for (const auto &v : out->indices) total += (int64_t)v.size();
+    *nnz = total;
+    return out;
+}
+
+extern "C" int tdgl_host_spgemm_take(void *handle, int64_t *indptr, int32_t *indices, double *data) {
+    auto *p = static_cast<Product *>(handle);
+    if (!p) return -1;
+    if (indptr) {
+        indptr[0] = 0;
+        for (int64_t i = 0; i < p->rows; ++i) indptr[i + 1] = indptr[i] + p->row_nnz[(size_t)i];
+        int64_t at = 0;
+        for (size_t t = 0; t < p->indices.size(); ++t) {
+            if (indices) std::copy(p->indices[t].begin(), p->indices[t].end(), indices + at);
+            if (data) std::copy(p->data[t].begin(), p->data[t].end(), data + at);
+            at += (int64_t)p->indices[t].size();
+        }
+    }
+    delete p;
+    return 0;
+}

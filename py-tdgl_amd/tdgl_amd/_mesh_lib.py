@@ -29,6 +29,8 @@ SIGNATURES = {
     "tdgl_host_lanczos": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _f64p, C.c_int, _f64p, C.c_int, _f64p, _f64p,
                                     C.POINTER(C.c_int), _f64p]),
     "tdgl_host_mis2_aggregate": (C.c_int, [C.c_int64, _i32p, _i32p, _f64p, _i64p, C.c_int, _i64p, _i64p]),
+    "tdgl_host_spgemm": (C.c_void_p, [C.c_int64, C.c_int64, _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, C.c_int, _i64p]),
+    "tdgl_host_spgemm_take": (C.c_int, [C.c_void_p, _i64p, _i32p, _f64p]),
     "tdgl_host_dual_mesh": (C.c_int, [C.c_int64, _f64p, C.c_int64, _i64p, _i64p, _i64p, _u8p, _i64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _u8p]),
 }
 
@@ -159,3 +161,39 @@ def mis2_aggregate(S, priority, threads=0):
     if rc != 0:
         raise ValueError(f"tdgl_host_mis2_aggregate: status {rc}")
     return agg, int(n_agg.value)
+
+
+def spgemm(A, B, threads=0):
+    """``A @ B`` for SciPy CSR matrices through `tdgl_host_spgemm` (include/tdgl_host_amg.h): sorted indices, exact
+    zeros not stored, the same result on any number of threads."""
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix(A)
+    B = sp.csr_matrix(B)
+    if A.shape[1] != B.shape[0]:
+        raise ValueError(f"dimension mismatch: {A.shape} @ {B.shape}")
+    if A.nnz >= 2**31 or B.nnz >= 2**31:
+        raise ValueError("matrix too large for 32-bit indices")
+    rows, cols = A.shape[0], B.shape[1]
+    if rows == 0 or cols == 0:
+        return sp.csr_matrix((rows, cols))
+    ap, ai = _csr32(A)
+    bp, bi = _csr32(B)
+    ad = np.ascontiguousarray(A.data, dtype=np.float64)
+    bd = np.ascontiguousarray(B.data, dtype=np.float64)
+    nnz = C.c_int64(0)
+    lib = load()
+    h = lib.tdgl_host_spgemm(rows, cols, ap.ctypes.data_as(_i32p), ai.ctypes.data_as(_i32p), ad.ctypes.data_as(_f64p),
+                             bp.ctypes.data_as(_i32p), bi.ctypes.data_as(_i32p), bd.ctypes.data_as(_f64p), int(threads),
+                             C.byref(nnz))
+    if not h:
+        raise ValueError("tdgl_host_spgemm: bad arguments")
+    indptr = np.empty(rows + 1, dtype=np.int64)
+    indices = np.empty(nnz.value, dtype=np.int32)
+    data = np.empty(nnz.value, dtype=np.float64)
+    lib.tdgl_host_spgemm_take(h, indptr.ctypes.data_as(_i64p), indices.ctypes.data_as(_i32p), data.ctypes.data_as(_f64p))
+    if nnz.value < 2**31:
+        indptr = indptr.astype(np.int32)
+    out = sp.csr_matrix((data, indices, indptr), shape=(rows, cols))
+    out.has_sorted_indices = True
+    return out

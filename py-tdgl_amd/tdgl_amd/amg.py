@@ -33,6 +33,18 @@ import numpy as np
 import scipy.sparse as sp
 
 
+def _mm(A, B):
+    """Sparse ``A @ B``: `tdgl_host_spgemm` (threaded, include/tdgl_host_amg.h) for the large products of the set-up,
+    SciPy for small ones.  Both give the same entries (SciPy's come out unsorted; they are sorted here as well)."""
+    if sp.issparse(A) and sp.issparse(B) and A.nnz + B.nnz > 200_000 and max(A.nnz, B.nnz) < 2**31:
+        from . import _mesh_lib
+
+        return _mesh_lib.spgemm(A, B)
+    C = (A @ B).tocsr()
+    C.sort_indices()
+    return C
+
+
 def _rowmax(indptr, vals, empty=-np.inf):
     """Row-wise max of CSR-ordered ``vals`` (rows may be empty)."""
     n = len(indptr) - 1
@@ -235,12 +247,12 @@ def build_hierarchy(
             break
         T = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, n_agg))
         DinvA = sp.diags(dinv) @ A
-        P = (T - (omega / rho) * (DinvA @ T)).tocsr()
+        P = (T - (omega / rho) * _mm(DinvA, T)).tocsr()
         P.sort_indices()
         R = P.T.tocsr()
         R.sort_indices()
         level.P, level.R, level.agg = P, R, agg
-        A = (R @ A @ P).tocsr()
+        A = _mm(R, _mm(A, P))
         A.sum_duplicates()
         A.sort_indices()
         # symmetrise round-off
@@ -290,7 +302,7 @@ def fused_restriction_from(A, R, dinv, c: float) -> sp.csr_matrix:
     A, R = sp.csr_matrix(A), sp.csr_matrix(R)
     n_own, n_loc = A.shape
     Rp = sp.hstack([R, sp.csr_matrix((R.shape[0], n_loc - n_own))]).tocsr() if n_loc > n_own else R
-    M = (Rp - (R @ A) @ sp.diags(c * np.asarray(dinv))).tocsr()
+    M = (Rp - _mm(R, A) @ sp.diags(c * np.asarray(dinv))).tocsr()
     M.sort_indices()
     return M
 
@@ -299,9 +311,9 @@ def fused_level_operators(level):
     """``(R A, A P, P on the pattern of A P)`` of a coarse level as CSR matrices / value array
     (`tdgl_poisson_set_fused_level`)."""
     A, P, R = level.A.tocsr(), level.P.tocsr(), level.R.tocsr()
-    RA = (R @ A).tocsr()
+    RA = _mm(R, A)
     RA.sort_indices()
-    AP = (A @ P).tocsr()
+    AP = _mm(A, P)
     # union pattern (P's pattern is contained in A P's whenever diag(A) != 0; do not rely on it),
     # then both value sets laid out on it (SciPy's sparse sum drops explicit zeros, so by hand)
     def keys(M):
@@ -407,15 +419,15 @@ def smoothing_operators(A, dinv, rho, nu=2, smoother="chebyshev", cheb_lo=0.1):
     # pre: d = c2[0] D b, x = d; then d = c1[k] d + c2[k] D (b - A x), x += d   (as operators on b)
     Dop, Xop = c2[0] * D, c2[0] * D
     for k in range(1, nu):
-        Dop = c1[k] * Dop + c2[k] * (D - DA @ Xop)
+        Dop = c1[k] * Dop + c2[k] * (D - _mm(DA, Xop))
         Xop = Xop + Dop
     S = sp.csr_matrix(Xop)
     # post: the polynomial restarts from x' with d = 0 (c1[0] = 0)
     Dx, Db = sp.csr_matrix((n, n)), sp.csr_matrix((n, n))
     Xx, Xb = eye, sp.csr_matrix((n, n))
     for k in range(nu):
-        Dx = c1[k] * Dx - c2[k] * (DA @ Xx)
-        Db = c1[k] * Db + c2[k] * (D - DA @ Xb)
+        Dx = c1[k] * Dx - c2[k] * _mm(DA, Xx)
+        Db = c1[k] * Db + c2[k] * (D - _mm(DA, Xb))
         Xx, Xb = Xx + Dx, Xb + Db
     Tx, Tb = sp.csr_matrix(Xx), sp.csr_matrix(Xb)
     for M in (S, Tx, Tb):
@@ -524,8 +536,7 @@ def collapsed_operators(h: Hierarchy, nu=2, smoother="chebyshev", cheb_lo=0.1, t
     for k in range(1, t):
         lv = h.levels[k]
         S, Tx, Tb = smoothing_operators(lv.A, lv.dinv, lv.rho, nu, smoother, cheb_lo)
-        M = (lv.R @ (sp.identity(sizes[k], format="csr") - lv.A @ S)).tocsr()
-        M.sort_indices()
+        M = _mm(lv.R, (sp.identity(sizes[k], format="csr") - _mm(lv.A, S)).tocsr())
         plan["mid"][k] = M
         if mid_up:
             # the way up of this level as explicit operators: e = (T_x S + T_b) b + (T_x P) e_next.  W is
@@ -533,13 +544,12 @@ def collapsed_operators(h: Hierarchy, nu=2, smoother="chebyshev", cheb_lo=0.1, t
             # tail's W' it sheds its small entries when the plan is not asked to reproduce the plain
             # cycle bit for bit (tail_cycles >= 2): 3e-3 keeps 46 per row at the same PCG iteration count
             # and convergence factor (0.303), 1e-2 38 per row at 0.304.  V = M^T is kept whole.
-            W = (Tx @ S + Tb).tocsr()
+            W = (_mm(Tx, S) + Tb).tocsr()
             W = ((W + W.T) * 0.5).tocsr()  # (round-off)
             if tail_cycles >= 2 and mid_drop_tol > 0:
                 W = _drop_small_symmetric(W, mid_drop_tol)
             W.sort_indices()
-            V = (Tx @ lv.P).tocsr()
-            V.sort_indices()
+            V = _mm(Tx, lv.P)
             plan["up"][k] = (W, V)
     lv = h.levels[t]
     if sizes[t] <= dense_rows:
@@ -548,12 +558,12 @@ def collapsed_operators(h: Hierarchy, nu=2, smoother="chebyshev", cheb_lo=0.1, t
             dense_cycle(h, t, nu, smoother, cheb_lo) if tail_cycles <= 1 else exact_pinv(lv.A))
         return plan
     S, Tx, Tb = smoothing_operators(lv.A, lv.dinv, lv.rho, nu, smoother, cheb_lo)
-    M = (lv.R @ (sp.identity(sizes[t], format="csr") - lv.A @ S)).tocsr()
+    M = _mm(lv.R, (sp.identity(sizes[t], format="csr") - _mm(lv.A, S)).tocsr())
     Bc = dense_cycle(h, t + 1, nu, smoother, cheb_lo)
     plan["mode"] = "gwv"
     G = Bc @ M.toarray()                                     # [n_{t+1}, n_t]
-    W = (Tx @ S + Tb).tocsr()
-    Vs = (Tx @ lv.P).tocsr()                                 # [n_t, n_{t+1}], a few entries per row
+    W = (_mm(Tx, S) + Tb).tocsr()
+    Vs = _mm(Tx, lv.P)                                 # [n_t, n_{t+1}], a few entries per row
     V = Vs.toarray()
     nt = sizes[t]
     if tail_cycles < 2:
@@ -567,12 +577,12 @@ def collapsed_operators(h: Hierarchy, nu=2, smoother="chebyshev", cheb_lo=0.1, t
         # B = W + V G;  B' = 2 B - B A B = W' + [V1 | -V] [G ; H]  with
         #   W' = 2 W - W A W,  K = G A V,  H = G A W,  V1 = 2 V - W A V - V K
         A = lv.A.tocsr()
-        AW = (A @ W).tocsr()
+        AW = _mm(A, W)
         H = np.asarray(G @ AW.toarray()) if AW.shape[0] <= 2048 else np.asarray((AW.T @ G.T).T)
         AV = A @ V
         K = G @ AV
         V1 = 2.0 * V - W @ AV - V @ K
-        W = (2.0 * W - W @ AW).tocsr()
+        W = (2.0 * W - _mm(W, AW)).tocsr()
         W = ((W + W.T) * 0.5).tocsr()  # (round-off)
         if drop_tol > 0:
             C = W.tocoo()

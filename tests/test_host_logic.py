@@ -35,7 +35,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
     mesh_lib = _mesh_lib.load()
     declared = sorted(_declared_functions("tdgl_host_mesh.h") + _declared_functions("tdgl_host_amg.h"))
-    assert sorted(_mesh_lib.SIGNATURES) == declared and len(declared) == 5
+    assert sorted(_mesh_lib.SIGNATURES) == declared and len(declared) == 7
     for name in declared:
         assert hasattr(mesh_lib, name), f"{name} declared in include/tdgl_host_mesh.h / tdgl_host_amg.h but not exported"
 
@@ -1283,3 +1283,34 @@ def test_native_lanczos_matches_the_numpy_recurrence_and_does_not_depend_on_thre
     v = np.ones(n) / np.sqrt(n)
     alpha, beta, g = _mesh_lib.lanczos(B, np.full(n, 0.5), v, 10)
     assert len(alpha) == 1 and beta[0] == 0.0 and abs(alpha[0] - 1.0) < 1e-15 and g == 1.0
+
+
+def test_native_spgemm_is_scipys_product_entry_for_entry():
+    """`tdgl_host_spgemm` accumulates every entry in SciPy's order (entries of A's row, then of B's row) and drops
+    exact zeros like SciPy: after sorting SciPy's rows the arrays are identical, on any number of threads."""
+    import scipy.sparse as sp
+
+    from tdgl_amd import _mesh_lib, amg
+
+    A, _ = _poisson_and_strength(70)
+    h = amg.build_hierarchy(A)
+    L0 = h.levels[0]
+    pairs = [(L0.A, L0.P), (L0.R, L0.A), (L0.R, (L0.A @ L0.P).tocsr()), (h.levels[1].A, h.levels[1].A),
+             (sp.random(300, 200, density=0.05, random_state=1, format="csr"), sp.random(200, 150, density=0.1, random_state=2, format="csr")),
+             (sp.csr_matrix((5, 7)), sp.random(7, 4, density=0.5, random_state=3, format="csr")),
+             (sp.csr_matrix(np.array([[1.0, 1.0], [0.0, 2.0]])), sp.csr_matrix(np.array([[1.0, 3.0], [-1.0, 0.5]])))]  # 1 - 1 = 0 is dropped
+    for X, Y in pairs:
+        want = (X @ Y).tocsr()
+        want.sort_indices()
+        for threads in (0, 1, 3):
+            got = _mesh_lib.spgemm(X, Y, threads=threads)
+            assert got.shape == want.shape and got.has_sorted_indices
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+            assert np.array_equal(got.data, want.data)
+    with pytest.raises(ValueError, match="mismatch"):
+        _mesh_lib.spgemm(sp.identity(3, format="csr"), sp.identity(4, format="csr"))
+    # the dispatcher: large products native, small ones SciPy, same result
+    big = amg._mm(L0.R, L0.A)
+    ref = (L0.R @ L0.A).tocsr()
+    ref.sort_indices()
+    assert np.array_equal(big.data, ref.data) and np.array_equal(big.indices, ref.indices)
