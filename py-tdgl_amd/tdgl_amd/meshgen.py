@@ -11,7 +11,7 @@ reference timing, so site counts match (L=70 -> 5,791; L=465 -> 250,510; L=930 -
 from typing import Tuple
 
 import numpy as np
-from scipy.spatial import Delaunay
+from scipy.spatial import Delaunay, cKDTree
 
 
 def hex_jitter_points(
@@ -99,13 +99,34 @@ def _points_in_poly(poly, pts):
     return mpath.Path(poly, closed=True).contains_points(pts)
 
 
-def _segment_distance(pts, a, b):
-    """Distance of every point to the segments a[k] -> b[k]; returns the minimum over segments."""
+def _segment_distance(pts, a, b, within=None):
+    """Distance of every point to the segments a[k] -> b[k]; returns the minimum over segments.
+
+    ``within``: the caller only compares the result with this threshold, so points farther than that from a
+    segment need not be measured (they keep ``inf``): a k-d tree hands every segment the points inside the
+    circle around its midpoint that contains the whole ``within``-neighbourhood, and the distance formula
+    runs on those alone -- the same numbers for every point that can fall below the threshold."""
     out = np.full(len(pts), np.inf)
-    for p0, p1 in zip(a, b):
+    if within is None or len(pts) < 2000:
+        for p0, p1 in zip(a, b):
+            d = p1 - p0
+            t = np.clip(((pts - p0) @ d) / (d @ d), 0.0, 1.0)
+            out = np.minimum(out, np.linalg.norm(pts - (p0 + t[:, None] * d), axis=1))
+        return out
+    from scipy.spatial import cKDTree
+
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    tree = cKDTree(pts)
+    reach = 0.5 * np.linalg.norm(b - a, axis=1) + float(within)
+    near = tree.query_ball_point(0.5 * (a + b), reach * (1 + 1e-9) + 1e-300)
+    for p0, p1, idx in zip(a, b, near):
+        if not idx:
+            continue
+        idx = np.asarray(idx)
+        q = pts[idx]
         d = p1 - p0
-        t = np.clip(((pts - p0) @ d) / (d @ d), 0.0, 1.0)
-        out = np.minimum(out, np.linalg.norm(pts - (p0 + t[:, None] * d), axis=1))
+        t = np.clip(((q - p0) @ d) / (d @ d), 0.0, 1.0)
+        out[idx] = np.minimum(out[idx], np.linalg.norm(q - (p0 + t[:, None] * d), axis=1))
     return out
 
 
@@ -152,19 +173,20 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
     lattice = lattice[keep]
     seg_a = np.concatenate(loops)
     seg_b = np.concatenate([np.roll(lp, -1, axis=0) for lp in loops])
-    lattice = lattice[_segment_distance(lattice, seg_a, seg_b) >= 0.6 * h]
+    lattice = lattice[_segment_distance(lattice, seg_a, seg_b, within=0.6 * h) >= 0.6 * h]
 
     for _ in range(max_rounds):
         nb = [len(b) for b in bloops]
         pts = np.concatenate(bloops + [lattice])
-        tri = Delaunay(pts).simplices
+        tri = triangulate(pts)
         cent = pts[tri].mean(axis=1)
         inside = _points_in_poly(loops[0], cent)
         for hole in loops[1:]:
             inside &= ~_points_in_poly(hole, cent)
         tri = tri[inside]
         edges = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
-        edge_set = set(map(tuple, edges))
+        edge_keys = np.unique(edges[:, 0] * np.int64(len(pts)) + edges[:, 1])
+        tree = cKDTree(pts)
         split = False
         off = 0
         new_loops = []
@@ -173,14 +195,19 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
             nxt = off + (np.arange(n_b) + 1) % n_b
             mids = 0.5 * (pts[idx] + pts[nxt])
             rad = 0.5 * np.linalg.norm(pts[nxt] - pts[idx], axis=1)
+            # (i) the segment is a triangle edge
+            keys = np.minimum(idx, nxt) * np.int64(len(pts)) + np.maximum(idx, nxt)
+            pos = np.searchsorted(edge_keys, keys)
+            present = (pos < len(edge_keys)) & (edge_keys[np.minimum(pos, len(edge_keys) - 1)] == keys)
+            # (ii) no other point strictly inside its diametral circle: the tree proposes, the distance decides
+            near = tree.query_ball_point(mids, rad)
             out = []
             for k in range(n_b):
-                present = (min(idx[k], nxt[k]), max(idx[k], nxt[k])) in edge_set
-                d = np.linalg.norm(pts - mids[k], axis=1)
-                d[[idx[k], nxt[k]]] = np.inf
-                encroached = bool((d < rad[k] * (1 - 1e-12)).any())
+                cand = np.asarray([j for j in near[k] if j != idx[k] and j != nxt[k]], dtype=np.int64)
+                encroached = bool(len(cand)) and bool(
+                    (np.linalg.norm(pts[cand] - mids[k], axis=1) < rad[k] * (1 - 1e-12)).any())
                 out.append(b[k])
-                if not present or encroached:
+                if not present[k] or encroached:
                     out.append(mids[k])
                     split = True
             new_loops.append(np.array(out))
@@ -194,7 +221,8 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
         seg_len = np.linalg.norm(bb - ba, axis=1)
         short = seg_len < 0.5 * h
         if short.any():
-            lattice = lattice[_segment_distance(lattice, ba[short], bb[short]) >= 0.6 * seg_len[short].max()]
+            thr = 0.6 * seg_len[short].max()
+            lattice = lattice[_segment_distance(lattice, ba[short], bb[short], within=thr) >= thr]
     else:  # pragma: no cover
         raise RuntimeError("polygon_mesh: boundary did not become conforming")
     used = np.unique(tri)

@@ -211,8 +211,10 @@ def test_polygon_mesher_with_holes_is_boundary_conforming():
     )
     dev.make_mesh(max_edge_length=0.8)
     mesh = dev.mesh
-    # the same mesher call produced the fixture: identical points, and the reference's dual mesh
-    assert np.array_equal(mesh.sites, g["mesh_sites"]) and np.array_equal(mesh.elements, g["mesh_elements"])
+    # the same mesher call produced the fixture: identical points and the same triangles (the fixture lists them in
+    # Qhull's order, the native triangulator in its own), and the reference's dual mesh
+    assert np.array_equal(mesh.sites, g["mesh_sites"])
+    assert np.array_equal(_triangle_set(mesh.elements), _triangle_set(g["mesh_elements"]))
     assert max_abs(mesh.areas, g["mesh_areas"]) < 1e-13
     em = mesh.edge_mesh
     assert em.edge_lengths.max() <= 0.8
@@ -1314,3 +1316,21 @@ def test_native_spgemm_is_scipys_product_entry_for_entry():
     ref = (L0.R @ L0.A).tocsr()
     ref.sort_indices()
     assert np.array_equal(big.data, ref.data) and np.array_equal(big.indices, ref.indices)
+
+
+def test_segment_distance_with_a_threshold_measures_the_same_near_points():
+    """`polygon_mesh` only asks which lattice points are closer than a threshold to the boundary: the k-d tree variant
+    must give exactly the brute-force distances wherever they are below it and leave the rest above."""
+    from tdgl_amd.meshgen import _segment_distance
+
+    rng = np.random.default_rng(3)
+    pts = rng.random((6000, 2)) * [30.0, 20.0]
+    a = rng.random((40, 2)) * [30.0, 20.0]
+    b = a + rng.standard_normal((40, 2)) * 1.5
+    full = _segment_distance(pts, a, b)
+    for within in (0.05, 0.4, 2.0):
+        fast = _segment_distance(pts, a, b, within=within)
+        near = full < within
+        assert near.any() and np.array_equal(fast[near], full[near])
+        assert (fast[~near] >= within).all()
+        assert np.array_equal(fast >= within, full >= within)
