@@ -17,8 +17,8 @@ extern "C" {
  * diagonal is not positive) from the unit start vector v0.  alpha[iters], beta[iters] receive the tridiagonal
  * matrix (beta[j] = norm of the j-th residual; a breakdown beta[j] <= 1e-12 max(|alpha[j]|, 1) ends the run with
  * beta[j] = 0), *steps the number of steps taken, *gershgorin max_i dinv_i sum_j |A_ij|.  Dot products are summed in
- * fixed blocks of 8192 entries, blocks in order: the same numbers for any thread count.  threads <= 0: up to 16,
- * never more than the hardware reports.  Returns 0, or -1 on bad arguments. */
+ * fixed blocks of 8192 entries, blocks in order: the same numbers for any thread count.  threads <= 0: up to 16 (or the
+ * environment variable TDGL_HOST_THREADS), never more than the hardware reports.  Returns 0, or -1 on bad arguments. */
 int tdgl_host_lanczos(int64_t n, const int32_t *indptr, const int32_t *indices, const double *data, const double *dinv,
                       int iters, const double *v0, int threads, double *alpha, double *beta, int *steps,
                       double *gershgorin);

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -55,6 +56,11 @@ int pick_threads(int requested, int64_t nblocks) {
     int hw = (int)std::thread::hardware_concurrency();
     if (hw < 1) hw = 1;
     int t = requested > 0 ? requested : std::min(16, hw);
+    if (requested <= 0)
+        if (const char *env = std::getenv("TDGL_HOST_THREADS")) {  // a shared node: cap the set-up's threads
+            const int v = std::atoi(env);
+            if (v > 0) t = v;
+        }
     t = std::min(t, hw);
     return (int)std::max<int64_t>(1, std::min<int64_t>(t, nblocks));
 }
