@@ -1334,3 +1334,42 @@ def test_segment_distance_with_a_threshold_measures_the_same_near_points():
         assert near.any() and np.array_equal(fast[near], full[near])
         assert (fast[~near] >= within).all()
         assert np.array_equal(fast >= within, full >= within)
+
+
+def test_native_delaunay_never_returns_an_illegal_triangulation_on_hostile_clouds():
+    """Small fuzz over the inputs a sweep-hull code finds hardest (integer grids full of repeats, lattices with
+    round-off noise, points on a circle at three scales, a nearly collinear strip, extreme magnitudes, tight clusters,
+    a parabola): it must terminate, every triangulation it returns must pass the exact in-circle check, and it must
+    own up (ERR_SKIPPED) whenever it left a point out."""
+    from tdgl_amd import _mesh_lib
+
+    rng = np.random.default_rng(123)
+    for case in range(160):
+        n = int(rng.integers(3, 600))
+        kind = case % 8
+        if kind == 0:
+            pts = rng.integers(0, 12, (n, 2)).astype(float)
+        elif kind == 1:
+            pts = rng.integers(0, 50, (n, 2)) + rng.standard_normal((n, 2)) * 1e-14
+        elif kind == 2:
+            a = rng.random(n) * 2 * np.pi
+            pts = np.column_stack([np.cos(a), np.sin(a)]) * rng.choice([1.0, 1e-8, 1e8])
+        elif kind == 3:
+            pts = np.column_stack([rng.random(n), rng.random(n) * 1e-12])
+        elif kind == 4:
+            pts = rng.standard_normal((n, 2)) * rng.choice([1e-150, 1.0, 1e150])
+        elif kind == 5:
+            pts = rng.random((5, 2))[rng.integers(0, 5, n)] + rng.standard_normal((n, 2)) * 1e-9
+        elif kind == 6:
+            t = rng.random(n)
+            pts = np.column_stack([t, t * t])
+        else:
+            pts = rng.random((n, 2)) + 1e7
+        pts = np.ascontiguousarray(pts)
+        status, tri = _mesh_lib.delaunay(pts)
+        if status == _mesh_lib.ERR_DEGENERATE:
+            continue
+        assert status in (_mesh_lib.OK, _mesh_lib.ERR_SKIPPED) and len(tri) > 0, (case, status)
+        assert _mesh_lib.is_delaunay(pts, tri), case
+        used = len(np.unique(tri))
+        assert used == n if status == _mesh_lib.OK else used < n, (case, status, used, n)
