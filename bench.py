@@ -467,7 +467,8 @@ def main():
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
             end_state=end_state, work=work, setup=setup, windows={},
-            stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats()), overlap=ctx.comm_overlap() if use_dd else None,
+            stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats(), batch_prediction=ctx.pcg_prediction_stats()),
+            overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
                        pcg_iters=np.concatenate([t["pcg_iters"] for t in trace]).tolist()),

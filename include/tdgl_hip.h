@@ -294,6 +294,14 @@ int tdgl_poisson_build_substructure(tdgl_ctx *ctx, const tdgl_substructure_plan 
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
  * solve, 1 if a captured iteration-pair graph is in use}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);
+/* How well the first batch of PCG iterations of a solve was sized.  The host queues a batch without looking at the
+ * residual; iterations beyond convergence freeze themselves but still cost their launches, a batch that is too short
+ * costs one more look per missing iteration.  The batch is ceil(log10(|r0| / (rtol |b|)) / rate - 1/4) with |r0| the
+ * residual of the initial guess -- known on the host from the guess's Gram data before anything is queued -- and
+ * `rate` the running mean of the decades per iteration observed so far (environment TDGL_PCG_PREDICT=last: the
+ * previous solve's count, the rule of rounds 1-3).  out3 = {iterations queued, iterations up to convergence, looks
+ * after the first batch} since the context was created; *rate (may be NULL) the current estimate. */
+int tdgl_get_pcg_prediction_stats(tdgl_ctx *ctx, int64_t *out3, double *rate);
 
 /* Storage of the V-cycle's operators in effect (after a solve): 0 fp64, 1 fp32, 2 fp32 and binary16 on
  * level 0 (tdgl_poisson_options.precond_fp32). */

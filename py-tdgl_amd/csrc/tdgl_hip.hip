@@ -364,6 +364,7 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     memset(ctx->h_status, 0, sizeof(StepStatus));
     ctx->status_copy = getenv("TDGL_STATUS_MAPPED") == nullptr;
     ctx->run_ahead_disabled = getenv("TDGL_NO_RUN_AHEAD") != nullptr;
+    if (const char *e = getenv("TDGL_PCG_PREDICT")) ctx->pcg_predict_from_guess = strcmp(e, "last") != 0;
     if (ctx->status_copy) {
         ctx->status_dev = ctx->d_status.p;
     } else {

@@ -385,6 +385,13 @@ struct tdgl_ctx {
     double last_guess_relres = 0.0;
     int32_t last_pcg_iters = 0;
     double last_relres = 0.0;
+    // how many iterations the first batch of a solve queues before the host looks (pcg_solve): predicted from the
+    // guess's residual, which the host knows from the Gram data, and the running contraction per iteration
+    double pcg_rate = 0.6;                // decades of ||r|| per iteration (running mean of the observed ones)
+    int32_t pcg_predict_from_guess = 1;   // 0: the previous solve's count (TDGL_PCG_PREDICT=last)
+    int64_t stat_pcg_launched = 0;        // iterations queued, frozen ones included
+    int64_t stat_pcg_needed = 0;          // iterations up to convergence
+    int64_t stat_pcg_extra_syncs = 0;     // host looks after the first batch of a solve
 
     // ---- step status / probes --------------------------------------------------------
     tdgl::DevBuf<double> psi_dmax_part;    // per-workgroup max d|psi|^2 of the last k_psi_update

@@ -201,6 +201,7 @@ SIGNATURES = {
     "tdgl_poisson_set_hierarchy": (C.c_int, [_CTX, C.POINTER(AmgLevel), C.c_int32, c_f64p]),
     "tdgl_set_poisson_options": (C.c_int, [_CTX, C.POINTER(PoissonOptions)]),
     "tdgl_get_poisson_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64)]),
+    "tdgl_get_pcg_prediction_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
     "tdgl_get_guess_stats": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
     "tdgl_get_guess_gram": (C.c_int, [_CTX, C.POINTER(C.c_int32), c_f64p]),
     "tdgl_host_solve_gram": (C.c_int, [C.c_int32, c_f64p, c_f64p, C.c_double, c_f64p, C.POINTER(C.c_int32)]),

@@ -858,6 +858,14 @@ class TDGLContext:
         self._chk(self._lib.tdgl_get_poisson_stats(self._ctx, out))
         return dict(fp64_fallbacks=out[0], last_iterations=out[1], graph=bool(out[2]))
 
+    def pcg_prediction_stats(self):
+        """``dict(queued, needed, extra_looks, rate)``: PCG iterations queued (frozen ones included) and needed since
+        the context was created, host looks after the first batch of a solve, and the running estimate of the
+        decades per iteration the batch size is predicted with (`tdgl_get_pcg_prediction_stats`)."""
+        out, rate = (C.c_int64 * 3)(), C.c_double(0)
+        self._chk(self._lib.tdgl_get_pcg_prediction_stats(self._ctx, out, C.byref(rate)))
+        return dict(queued=out[0], needed=out[1], extra_looks=out[2], rate=rate.value)
+
     def guess_stats(self):
         """``dict(vectors, initial_relres)`` of the last solve's initial guess."""
         k, r = C.c_int32(0), C.c_double(0)

@@ -347,6 +347,50 @@ def test_guess_window_sizes_and_a_window_change_on_a_live_context():
     assert max_abs(live[2]["mu"], ref[2]["mu"]) < 1e-8 * max(1.0, np.abs(ref[2]["mu"]).max())
 
 
+def test_first_batch_of_iterations_is_sized_from_the_guess_and_changes_nothing():
+    """The number of PCG iterations queued before the host looks is predicted from the residual of the initial guess
+    (known on the host from the Gram data) and the observed contraction per iteration; iterations queued beyond
+    convergence freeze themselves.  So: bit-identical fields and iteration counts with the old rule (the previous
+    solve's count, TDGL_PCG_PREDICT=last), no fewer iterations queued than needed, and fewer frozen ones than the old
+    rule queues once the run has left its first steps."""
+    import os
+
+    from tdgl_amd import SolverOptions, TDGLSolver
+
+    mesh = synthetic_mesh(150)
+    A = uniform_field_A(mesh, 0.1)
+    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=1000, sparse_solver="amg_pcg")
+
+    def run(rule):
+        old = os.environ.pop("TDGL_PCG_PREDICT", None)
+        if rule:
+            os.environ["TDGL_PCG_PREDICT"] = rule
+        try:
+            solver = TDGLSolver.from_dimensionless(mesh, opts, A, 1.0)  # (the switch is read when the context is created)
+        finally:
+            os.environ.pop("TDGL_PCG_PREDICT", None)
+            if old is not None:
+                os.environ["TDGL_PCG_PREDICT"] = old
+        ctx = solver.ctx
+        ctx.set_state(solver.psi_init, solver.mu_init)
+        ctx.begin_stage()
+        res = ctx.run(260)
+        out = (res["dt"], res["pcg_iters"], ctx.get_state(), ctx.pcg_prediction_stats())
+        ctx.close()
+        return out
+
+    new, last = run(None), run("last")
+    assert np.array_equal(new[0], last[0]) and np.array_equal(new[1], last[1])
+    for f in ("psi", "mu", "supercurrent", "normal_current"):
+        assert np.array_equal(new[2][f], last[2][f]), f
+    for st in (new[3], last[3]):
+        assert st["needed"] == int(new[1].sum()) and st["queued"] >= st["needed"]
+        assert 0.2 <= st["rate"] <= 1.5
+    waste_new, waste_last = new[3]["queued"] - new[3]["needed"], last[3]["queued"] - last[3]["needed"]
+    assert waste_new <= waste_last and waste_new <= 0.15 * new[3]["needed"]
+    assert new[3]["extra_looks"] <= 0.6 * len(new[1])
+
+
 @pytest.mark.parametrize("k,n", [(3, 2001), (8, 70000), (12, 5001), (16, 4096)])
 def test_guess_dot_products_are_double_double_exact(small_ctx, k, n):
     """k_multi_dot (all three compiled windows, odd / even lengths, one and many workgroups): every sum of

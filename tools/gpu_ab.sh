@@ -13,7 +13,7 @@ for V in "$@"; do
 import json,sys
 try:
     d=json.load(open('gpurun_out/ab_tmp.json'))
-    print(json.dumps(dict(variant=sys.argv[1], value=d['value'], ms=d['ms_per_step'], its=d['pcg']['mean_iterations'], k1=d['roofline']['frac'], axp_ms=(d.get('roofline_pcg') or {}).get('avg_launch_ms'), agg=d['step_aggregate']['frac_of_hbm_peak'])))
+    print(json.dumps(dict(variant=sys.argv[1], value=d['value'], ms=d['ms_per_step'], its=d['pcg']['mean_iterations'], pred=d['pcg'].get('batch_prediction'), k1=d['roofline']['frac'], axp_ms=(d.get('roofline_pcg') or {}).get('avg_launch_ms'), agg=d['step_aggregate']['frac_of_hbm_peak'])))
 except Exception as e:
     print(json.dumps(dict(variant=sys.argv[1], error=str(e))))
 PY
