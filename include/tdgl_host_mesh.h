@@ -21,9 +21,8 @@ extern "C" {
 #define TDGL_MESH_OK 0
 #define TDGL_MESH_ERR_ARG (-1)        /* null pointer, fewer than three points, a non-finite coordinate */
 #define TDGL_MESH_ERR_DEGENERATE (-2) /* all points collinear (or coincident) */
-#define TDGL_MESH_ERR_SKIPPED (-3)    /* points were left out: each repeats another point, or lies within rounding of one
-                                         (the sweep order is computed in floating point), or the cloud is collinear to
-                                         within rounding; the triangulation of the others is returned and is legal */
+#define TDGL_MESH_ERR_SKIPPED (-3)    /* points that coincide with another point were left out; the triangulation of the
+                                         distinct points is returned */
 #define TDGL_MESH_ERR_INDEX (-4)      /* a triangle refers to a site that does not exist */
 
 /* Delaunay triangulation of `n` points `xy[2 i], xy[2 i + 1]` (sweep-hull insertion in order of distance from

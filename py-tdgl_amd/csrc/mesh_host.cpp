@@ -5,7 +5,9 @@
 //
 // Delaunay: points are inserted in order of distance from the circumcentre of a seed triangle, so every
 // new point lies outside the convex hull of the points before it; it is connected to the hull edges it
-// sees, and edges that fail the in-circle test are flipped (Lawson).  The hull is a doubly linked ring
+// sees, and edges that fail the in-circle test are flipped (Lawson).  (The order is computed in floating
+// point: a point that turns out to lie inside the hull or on it is located by a walk and inserted into its
+// triangle or onto its edge; only a point that coincides with another one is left out, and reported.)  The hull is a doubly linked ring
 // with an angular hash to find a visible edge in O(1).  Orientation and in-circle signs are exact: a
 // forward error bound decides almost always (Shewchuk's stage-A bounds), otherwise the determinant is
 // evaluated in exact expansion arithmetic.
@@ -238,6 +240,103 @@ struct Triangulator {
         return flips;
     }
 
+    int new_slots(int a, int b, int c) {  // three half-edges a -> b -> c -> a without twins yet
+        const int h = (int)tri.size();
+        tri.push_back(a);
+        tri.push_back(b);
+        tri.push_back(c);
+        twin.push_back(-1);
+        twin.push_back(-1);
+        twin.push_back(-1);
+        return h;
+    }
+    // The triangle that contains p (p sees no hull edge, so it is inside the hull or on its boundary): a walk from
+    // half-edge `h`, always across an edge that has p strictly on its far side; in a Delaunay triangulation such a
+    // walk ends.  Returns a half-edge of the triangle, or -1 (cannot happen with exact predicates).
+    int locate(const double *p, int h) const {
+        const int64_t limit = 2 * (int64_t)tri.size() + 16;
+        for (int64_t step = 0; step < limit; ++step) {
+            const int t = h - h % 3;
+            int cross = -1;
+            for (int k = 0; k < 3 && cross < 0; ++k) {
+                const int e = t + k;
+                if (orient(pt(tri[e]), pt(tri[next(e)]), p) < 0.0) cross = e;
+            }
+            if (cross < 0) return t;
+            if (twin[cross] < 0) return -1;
+            h = twin[cross];
+        }
+        for (int t = 0; t < (int)tri.size(); t += 3) {  // (a walk that does not end: look at every triangle)
+            bool in = true;
+            for (int k = 0; k < 3 && in; ++k) in = !(orient(pt(tri[t + k]), pt(tri[next(t + k)]), p) < 0.0);
+            if (in) return t;
+        }
+        return -1;
+    }
+    // Insert point i, which sees no hull edge.  0: inserted; 1: it coincides with a point of the triangulation
+    // (left out); -1: not located.
+    int insert_inside(int i, int start_edge) {
+        const double *p = pt(i);
+        const int t = locate(p, start_edge);
+        if (t < 0) return -1;
+        int zero_edge = -1, zeros = 0;
+        for (int k = 0; k < 3; ++k)
+            if (orient(pt(tri[t + k]), pt(tri[next(t + k)]), p) == 0.0) zero_edge = t + k, ++zeros;
+        if (zeros >= 2) return 1;  // on two edge lines of its triangle: a vertex
+        if (zeros == 0) {
+            // (a, b, c) -> (a, b, p), (b, c, p), (c, a, p)
+            const int h0 = t, h1 = t + 1, h2 = t + 2;
+            const int b = tri[h1], c = tri[h2], a = tri[h0];
+            const int t1 = twin[h1], t2 = twin[h2];
+            tri[h2] = i;
+            const int g = new_slots(b, c, i), k = new_slots(c, a, i);
+            link(g, t1);
+            link(k, t2);
+            twin[h1] = g + 2, twin[g + 2] = h1;  // b -> p | p -> b
+            twin[g + 1] = k + 2, twin[k + 2] = g + 1;  // c -> p | p -> c
+            twin[h2] = k + 1, twin[k + 1] = h2;  // p -> a | a -> p
+            legalize(h0);
+            legalize(g);
+            legalize(k);
+            return 0;
+        }
+        // on the edge e = u -> v of (u, v, w): (u, p, w) + (p, v, w); the triangle across, (v, u, x), likewise
+        const int e = zero_edge, e1 = next(e), e2 = prev(e);
+        const int v = tri[e1], w = tri[e2], u = tri[e];
+        const int f = twin[e], t_vw = twin[e1];
+        tri[e1] = i;                           // e: u -> p, e1: p -> w, e2: w -> u
+        const int nn = new_slots(i, v, w);     // p -> v, v -> w, w -> p
+        link(nn + 1, t_vw);
+        twin[e1] = nn + 2, twin[nn + 2] = e1;
+        if (f >= 0) {
+            const int f1 = next(f), f2 = prev(f);
+            const int x = tri[f2];
+            const int t_ux = twin[f1];
+            tri[f1] = i;                        // f: v -> p, f1: p -> x, f2: x -> v
+            const int m = new_slots(i, u, x);   // p -> u, u -> x, x -> p
+            link(m + 1, t_ux);
+            twin[f1] = m + 2, twin[m + 2] = f1;
+            twin[e] = m, twin[m] = e;           // u -> p | p -> u
+            twin[nn] = f, twin[f] = nn;         // p -> v | v -> p
+            legalize(e2);
+            legalize(nn + 1);
+            legalize(f2);
+            legalize(m + 1);
+        } else {
+            // a hull edge: p joins the ring between u and v
+            link(e, -1);   // hull_edge[u] = e
+            link(nn, -1);  // hull_edge[p] = nn
+            hull_next[u] = i;
+            hull_prev[i] = u;
+            hull_next[i] = v;
+            hull_prev[v] = i;
+            hash[hash_key(p)] = i;
+            legalize(e2);
+            legalize(nn + 1);
+        }
+        return 0;
+    }
+
     int run(int64_t *out, int64_t *n_out) {
         // bounding box, seed triangle
         double lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
@@ -335,8 +434,10 @@ struct Triangulator {
                 }
                 q = hull_next[e];
             }
-            if (!found) {  // p sees no edge: it coincides with a point that is already in
-                ++skipped;
+            if (!found) {
+                // p sees no hull edge: it is not outside the hull after all -- it repeats a point, or rounding in the
+                // sweep order let a point farther out go first.  Insert it into the triangle that contains it.
+                if (insert_inside(i, hull_edge[start]) != 0) ++skipped;
                 continue;
             }
             // walk back: the search may have started inside the visible chain

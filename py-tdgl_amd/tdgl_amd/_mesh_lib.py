@@ -63,8 +63,8 @@ def _xy(points):
 
 
 def delaunay(points):
-    """``(status, triangles[t, 3] int64)``, counter-clockwise.  status: OK, ERR_SKIPPED (repeated points
-    were left out; the triangulation of the others is returned), ERR_DEGENERATE (all collinear)."""
+    """``(status, triangles[t, 3] int64)``, counter-clockwise.  status: OK, ERR_SKIPPED (coinciding points
+    were left out; the triangulation of the distinct points is returned), ERR_DEGENERATE (all collinear)."""
     pts = _xy(points)
     n = len(pts)
     if n < 3:

@@ -56,8 +56,7 @@ def triangulate(points: np.ndarray, backend: str = "native") -> np.ndarray:
     ``backend="native"``: `tdgl_host_delaunay` (include/tdgl_host_mesh.h; sweep-hull insertion with exact
     predicates, counter-clockwise triangles) -- 0.9 s per million points where Qhull takes 7.7 s, the same
     set of triangles for points in general position.  ``"qhull"``: `scipy.spatial.Delaunay`.  A point cloud
-    with repeated points (or points within rounding of each other: the native code reports what it left out) goes to
-    Qhull as before."""
+    with coinciding points (the native code leaves the repeats out and says so) goes to Qhull as before."""
     if backend == "native":
         from . import _mesh_lib
 

@@ -1339,14 +1339,14 @@ def test_segment_distance_with_a_threshold_measures_the_same_near_points():
 def test_native_delaunay_never_returns_an_illegal_triangulation_on_hostile_clouds():
     """Small fuzz over the inputs a sweep-hull code finds hardest (integer grids full of repeats, lattices with
     round-off noise, points on a circle at three scales, a nearly collinear strip, extreme magnitudes, tight clusters,
-    a parabola): it must terminate, every triangulation it returns must pass the exact in-circle check, and it must
-    own up (ERR_SKIPPED) whenever it left a point out."""
+    a parabola, midpoints of lattice edges): it must terminate, every triangulation it returns must pass the exact
+    in-circle check and use every distinct point, and it must own up (ERR_SKIPPED) exactly when points coincide."""
     from tdgl_amd import _mesh_lib
 
     rng = np.random.default_rng(123)
-    for case in range(160):
+    for case in range(180):
         n = int(rng.integers(3, 600))
-        kind = case % 8
+        kind = case % 9
         if kind == 0:
             pts = rng.integers(0, 12, (n, 2)).astype(float)
         elif kind == 1:
@@ -1363,13 +1363,19 @@ def test_native_delaunay_never_returns_an_illegal_triangulation_on_hostile_cloud
         elif kind == 6:
             t = rng.random(n)
             pts = np.column_stack([t, t * t])
-        else:
+        elif kind == 7:
             pts = rng.random((n, 2)) + 1e7
+        else:
+            g = np.stack(np.meshgrid(np.arange(8.0), np.arange(8.0)), -1).reshape(-1, 2)
+            pts = np.concatenate([g, 0.5 * (g[rng.integers(0, 64, n)] + g[rng.integers(0, 64, n)])])
         pts = np.ascontiguousarray(pts)
         status, tri = _mesh_lib.delaunay(pts)
         if status == _mesh_lib.ERR_DEGENERATE:
             continue
         assert status in (_mesh_lib.OK, _mesh_lib.ERR_SKIPPED) and len(tri) > 0, (case, status)
         assert _mesh_lib.is_delaunay(pts, tri), case
-        used = len(np.unique(tri))
-        assert used == n if status == _mesh_lib.OK else used < n, (case, status, used, n)
+        distinct = len(np.unique(pts, axis=0))
+        # every distinct point is a vertex (points that the sweep order misplaced are inserted into their triangle
+        # or onto their edge); only coinciding points are left out, and exactly then the status says so
+        assert len(np.unique(tri)) == distinct, (case, status)
+        assert (status == _mesh_lib.OK) == (distinct == n), (case, status)
