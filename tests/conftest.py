@@ -14,6 +14,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The libraries are build products (git-ignored): make sure they exist and are current before anything imports
+    # them -- the meshes of nearly every test come from libtdgl_mesh.so.  (A no-op when they are up to date; on a
+    # machine without the compilers the tests that need a library fail on their own.)
+    try:
+        import __graft_entry__ as entry
+
+        entry.build()
+    except Exception as exc:  # pragma: no cover
+        print(f"conftest: could not build the libraries ({exc!r})", file=sys.stderr)
 
 
 def load_golden(name):
