@@ -822,5 +822,19 @@ def main():
         sys.exit(3)
 
 
+def _libraries_present():
+    """The libraries are build products that travel with the tree; should one be missing in a single-process run,
+    build it here (ranks of a multi-process run must not race for the compiler: there the tree has to be built first)."""
+    lib_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "py-tdgl_amd", "tdgl_amd", "lib")
+    if all(os.path.exists(os.path.join(lib_dir, f)) for f in ("libtdgl_hip.so", "libtdgl_mesh.so")):
+        return
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("bench.py: libraries not built -- run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    import __graft_entry__ as entry
+
+    entry.build()
+
+
 if __name__ == "__main__":
+    _libraries_present()
     main()
