@@ -402,7 +402,8 @@ int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary);
  *     (one per terminal) covers the boundary-edge POSITIONS group_pos[group_ptr[g] .. group_ptr[g+1])
  *     and carries the current density density[g * n_nodes + k] at times[k] (already
  *     -(1/length_g) * sum of the other terminals' currents); mu_boundary is refreshed only in steps
- *     where a density changed, like the reference.  Densities and mu_boundary start at 0.
+ *     where a density changed, like the reference.  Densities and mu_boundary start at 0.  In the run-ahead loop
+ *     (tdgl_run) the device evaluates the table itself, with the host's arithmetic operation for operation.
  *   tdgl_set_epsilon_table: epsilon(r, t) = factor(t) * epsilon0(r) (update_epsilon, solver.py:364-381,
  *     for a separable disorder parameter).
  * n_nodes = 0 switches a table off. */
@@ -472,7 +473,8 @@ int tdgl_begin_stage(tdgl_ctx *ctx);
  *   reached_end          1 if the loop ended because time >= end_time
  * Returns TDGL_ERR_PSI_RETRIES with the reference's message when the psi update fails.
  * With a direct mu solve (tdgl_poisson_build_dense_inverse / _build_substructure), static link variables,
- * no tables and no screening the loop runs AHEAD of the host: the retry decision (solver.py:475-485), the
+ * no epsilon table and no screening (terminal-current tables are fine: the device evaluates them at the time
+ * of every attempt) the loop runs AHEAD of the host: the retry decision (solver.py:475-485), the
  * adaptive-dt controller (:698-707) and this loop's bookkeeping execute on the device and the host
  * synchronises once per batch of up to 64 attempts -- outputs, errors and the state left behind are
  * bit-identical to the one-synchronisation-per-step loop (environment TDGL_NO_RUN_AHEAD=1 forces that one). */

@@ -798,6 +798,27 @@ extern "C" int tdgl_set_mu_boundary_table(tdgl_ctx *ctx, int32_t n_nodes, const 
     ctx->tab_mu_pos.assign(group_pos, group_pos + group_ptr[n_groups]);
     ctx->tab_mu_last.assign(n_groups, 0.0);                        // solver.py:323: densities start at 0
     ctx->tab_mu_host.assign(std::max<int64_t>(ctx->nb, 1), 0.0);  // ... and mu_boundary at 0 (solver.py:289)
+    // device copy for the run-ahead loop (k_ra_mu_table); single-GPU contexts only, like that loop
+    ctx->tab_mu_on_device = false;
+    if (ctx->nb > 0 && ctx->n_own == ctx->n) {
+        std::vector<int32_t> group((size_t)ctx->nb, -1);
+        for (int32_t g = 0; g < n_groups; ++g)
+            for (int32_t k = group_ptr[g]; k < group_ptr[g + 1]; ++k) group[(size_t)group_pos[k]] = g;
+        HIP_TRY(ctx, ctx->d_tab_mu_group.upload(group));
+        HIP_TRY(ctx, ctx->d_tab_mu_t.upload(ctx->tab_mu_t));
+        HIP_TRY(ctx, ctx->d_tab_mu_dens.upload(ctx->tab_mu_dens));
+        if (ctx->d_b_sites.n == 0) {
+            std::vector<int32_t> s0((size_t)ctx->nb), s1((size_t)ctx->nb);
+            HIP_TRY(ctx, hipMemcpy(s0.data(), ctx->b_s0.p, s0.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(s1.data(), ctx->b_s1.p, s1.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            s0.insert(s0.end(), s1.begin(), s1.end());
+            std::sort(s0.begin(), s0.end());
+            s0.erase(std::unique(s0.begin(), s0.end()), s0.end());
+            HIP_TRY(ctx, ctx->d_b_sites.upload(s0));
+            ctx->n_b_sites = (int32_t)s0.size();
+        }
+        ctx->tab_mu_on_device = true;
+    }
     return TDGL_OK;
 }
 

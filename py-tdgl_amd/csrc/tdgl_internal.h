@@ -259,6 +259,12 @@ struct tdgl_ctx {
     std::vector<double> tab_mu_t, tab_mu_dens;       // nodes; densities [n_groups x n_nodes]
     std::vector<int32_t> tab_mu_ptr, tab_mu_pos;     // groups of boundary-edge positions (CSR-like)
     std::vector<double> tab_mu_last, tab_mu_host;    // last densities applied; host copy of mu_boundary
+    // the same table on the device, for the run-ahead loop (k_ra_mu_table evaluates it at the device's own time)
+    tdgl::DevBuf<double> d_tab_mu_t, d_tab_mu_dens;
+    tdgl::DevBuf<int32_t> d_tab_mu_group;            // [nb]: group of a boundary position, -1 = not tabulated
+    tdgl::DevBuf<int32_t> d_b_sites;                 // the sites that boundary edges touch, each once
+    int32_t n_b_sites = 0;
+    bool tab_mu_on_device = false;
     std::vector<double> tab_eps_t, tab_eps_f;
     tdgl::DevBuf<double> tab_eps0;                   // static part of epsilon, internal site order
     double tab_eps_last = NAN;
