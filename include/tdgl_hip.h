@@ -473,8 +473,8 @@ int tdgl_begin_stage(tdgl_ctx *ctx);
  *   reached_end          1 if the loop ended because time >= end_time
  * Returns TDGL_ERR_PSI_RETRIES with the reference's message when the psi update fails.
  * With a direct mu solve (tdgl_poisson_build_dense_inverse / _build_substructure), static link variables,
- * no epsilon table and no screening (terminal-current tables are fine: the device evaluates them at the time
- * of every attempt) the loop runs AHEAD of the host: the retry decision (solver.py:475-485), the
+ * and no screening (the tables of tdgl_set_mu_boundary_table / tdgl_set_epsilon_table are fine: the device
+ * evaluates them at the time of every attempt) the loop runs AHEAD of the host: the retry decision (solver.py:475-485), the
  * adaptive-dt controller (:698-707) and this loop's bookkeeping execute on the device and the host
  * synchronises once per batch of up to 64 attempts -- outputs, errors and the state left behind are
  * bit-identical to the one-synchronisation-per-step loop (environment TDGL_NO_RUN_AHEAD=1 forces that one). */

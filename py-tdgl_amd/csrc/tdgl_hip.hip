@@ -834,6 +834,12 @@ extern "C" int tdgl_set_epsilon_table(tdgl_ctx *ctx, const double *epsilon0, int
     ctx->tab_eps_t.assign(times, times + n_nodes);
     ctx->tab_eps_f.assign(factor, factor + n_nodes);
     ctx->tab_eps_last = NAN;
+    ctx->tab_eps_on_device = false;
+    if (ctx->n_own == ctx->n) {  // device copy for the run-ahead loop
+        HIP_TRY(ctx, ctx->d_tab_eps_t.upload(ctx->tab_eps_t));
+        HIP_TRY(ctx, ctx->d_tab_eps_f.upload(ctx->tab_eps_f));
+        ctx->tab_eps_on_device = true;
+    }
     return TDGL_OK;
 }
 

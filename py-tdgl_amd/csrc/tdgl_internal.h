@@ -265,6 +265,8 @@ struct tdgl_ctx {
     tdgl::DevBuf<int32_t> d_b_sites;                 // the sites that boundary edges touch, each once
     int32_t n_b_sites = 0;
     bool tab_mu_on_device = false;
+    tdgl::DevBuf<double> d_tab_eps_t, d_tab_eps_f;   // the epsilon factor's table on the device (k_ra_eps_table)
+    bool tab_eps_on_device = false;
     std::vector<double> tab_eps_t, tab_eps_f;
     tdgl::DevBuf<double> tab_eps0;                   // static part of epsilon, internal site order
     double tab_eps_last = NAN;
