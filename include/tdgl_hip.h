@@ -292,7 +292,8 @@ typedef struct {
 } tdgl_substructure_plan;
 int tdgl_poisson_build_substructure(tdgl_ctx *ctx, const tdgl_substructure_plan *plan, double *seconds);
 /* out3 = {solves that fell back from the fp32-stored to the fp64 operators, iterations of the last
- * solve, 1 if a captured iteration-pair graph is in use}. */
+ * solve, 0 (was: a captured iteration-pair hipGraph in use; the replay was removed in round 5, plain launches are
+ * faster since ROCm 7.2 -- profiles/EXPERIMENTS.md)}. */
 int tdgl_get_poisson_stats(tdgl_ctx *ctx, int64_t *out3);
 /* How well the first batch of PCG iterations of a solve was sized.  The host queues a batch without looking at the
  * residual; iterations beyond convergence freeze themselves but still cost their launches, a batch that is too short

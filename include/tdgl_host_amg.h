@@ -3,6 +3,8 @@
  * hierarchy is this port's counterpart of the reference's sparse LU factorisation of the mu Laplacian
  * (tdgl/finite_volume/operators.py:305-308).  Plain C++ with std::thread (no OpenMP runtime: safe across fork),
  * built into libtdgl_mesh.so next to include/tdgl_host_mesh.h.  Results do not depend on the number of threads.
+ * No C++ exception leaves these functions: running out of memory or of threads inside a call returns -5 (NULL from
+ * tdgl_host_spgemm), the thread team is wound down first.
  */
 #ifndef TDGL_HOST_AMG_H
 #define TDGL_HOST_AMG_H

@@ -24,6 +24,7 @@ extern "C" {
 #define TDGL_MESH_ERR_SKIPPED (-3)    /* points that coincide with another point were left out; the triangulation of the
                                          distinct points is returned */
 #define TDGL_MESH_ERR_INDEX (-4)      /* a triangle refers to a site that does not exist */
+#define TDGL_MESH_ERR_RESOURCES (-5)  /* out of memory inside the call (no C++ exception leaves the library) */
 
 /* Delaunay triangulation of `n` points `xy[2 i], xy[2 i + 1]` (sweep-hull insertion in order of distance from
  * a seed circumcentre, edge flips with exact orientation / in-circle predicates: a floating-point filter first,

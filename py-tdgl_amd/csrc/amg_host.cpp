@@ -10,6 +10,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
+#include <memory>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -17,20 +19,27 @@ namespace {
 
 constexpr int64_t BLOCK_ROWS = 8192;
 
+// Thrown inside `barrier()` of the members that are still running once one member has failed.
+struct TeamAborted {};
+
 class Team {
   public:
     explicit Team(int threads) : n_(std::max(1, threads)) {}
     int size() const { return n_; }
-    // all members call this; returns when every one has arrived
+    // all members call this; returns when every one has arrived (or leaves by exception when a member has failed:
+    // nobody spins for a thread that will never come)
     void barrier() {
+        if (abort_.load(std::memory_order_acquire)) throw TeamAborted{};
         const int gen = generation_.load(std::memory_order_acquire);
         if (arrived_.fetch_add(1, std::memory_order_acq_rel) + 1 == n_) {
             arrived_.store(0, std::memory_order_relaxed);
             generation_.store(gen + 1, std::memory_order_release);
         } else {
             int spins = 0;
-            while (generation_.load(std::memory_order_acquire) == gen)
+            while (generation_.load(std::memory_order_acquire) == gen) {
+                if (abort_.load(std::memory_order_acquire)) throw TeamAborted{};
                 if (++spins > 2000) std::this_thread::yield();
+            }
         }
     }
     // the rows [begin, end) of member `tid` when `nblocks` blocks are dealt out in contiguous runs
@@ -38,19 +47,44 @@ class Team {
         b0 = nblocks * tid / members;
         b1 = nblocks * (tid + 1) / members;
     }
+    // Runs body(0..n-1) on n threads.  A member that throws (std::bad_alloc in its scratch arrays), or a thread that
+    // cannot be created (std::system_error under a pid limit), aborts the team: the others leave at their next
+    // barrier, everything is joined, and std::runtime_error is thrown to the caller -- the extern "C" entry points
+    // turn it into an error code, no exception crosses the C boundary.
     void run(const std::function<void(int)> &body) {
+        std::atomic<bool> go{false};
+        auto member = [&](int t) {
+            while (!go.load(std::memory_order_acquire)) {
+                if (abort_.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            try {
+                body(t);
+            } catch (...) {
+                abort_.store(true, std::memory_order_release);
+            }
+        };
         std::vector<std::thread> others;
-        others.reserve((size_t)n_ - 1);
-        for (int t = 1; t < n_; ++t) others.emplace_back(body, t);
-        body(0);
+        try {
+            others.reserve((size_t)n_ - 1);
+            for (int t = 1; t < n_; ++t) others.emplace_back(member, t);
+        } catch (...) {
+            abort_.store(true, std::memory_order_release);
+        }
+        go.store(true, std::memory_order_release);
+        member(0);
         for (auto &t : others) t.join();
+        if (abort_.load(std::memory_order_acquire)) throw std::runtime_error("thread team aborted");
     }
 
   private:
     int n_;
     std::atomic<int> arrived_{0};
     std::atomic<int> generation_{0};
+    std::atomic<bool> abort_{false};
 };
+
+constexpr int ERR_RESOURCES = -5;  // out of memory / threads inside a call (include/tdgl_host_amg.h)
 
 int pick_threads(int requested, int64_t nblocks) {
     int hw = (int)std::thread::hardware_concurrency();
@@ -71,6 +105,7 @@ extern "C" int tdgl_host_lanczos(int64_t n, const int32_t *indptr, const int32_t
                                  int iters, const double *v0, int threads, double *alpha, double *beta, int *steps,
                                  double *gershgorin) {
     if (n < 1 || !indptr || !indices || !data || !dinv || !v0 || !alpha || !beta || !steps || !gershgorin || iters < 1) return -1;
+    try {
     const int64_t nblocks = (n + BLOCK_ROWS - 1) / BLOCK_ROWS;
     Team team(pick_threads(threads, nblocks));
     std::vector<double> sq((size_t)n), va(v0, v0 + n), vb((size_t)n, 0.0), vc((size_t)n);
@@ -154,11 +189,15 @@ extern "C" int tdgl_host_lanczos(int64_t n, const int32_t *indptr, const int32_t
     (void)stop;
     *steps = done;
     return 0;
+    } catch (...) {
+        return ERR_RESOURCES;
+    }
 }
 
 extern "C" int tdgl_host_mis2_aggregate(int64_t n, const int32_t *indptr, const int32_t *indices, const double *weight,
                                         const int64_t *priority, int threads, int64_t *agg, int64_t *n_agg) {
     if (n < 1 || !indptr || !indices || !weight || !priority || !agg || !n_agg) return -1;
+    try {
     const int64_t nblocks = (n + BLOCK_ROWS - 1) / BLOCK_ROWS;
     Team team(pick_threads(threads, nblocks));
     std::vector<int8_t> state((size_t)n, 0), root((size_t)n), near1((size_t)n);
@@ -244,6 +283,9 @@ extern "C" int tdgl_host_mis2_aggregate(int64_t n, const int32_t *indptr, const 
         if (agg[i] < 0) agg[i] = roots++;  // (cannot happen for a maximal MIS(2))
     *n_agg = roots;
     return 0;
+    } catch (...) {
+        return ERR_RESOURCES;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -265,11 +307,12 @@ extern "C" void *tdgl_host_spgemm(int64_t rows, int64_t cols, const int32_t *a_i
                                   const int32_t *b_indptr, const int32_t *b_indices, const double *b_data, int threads, int64_t *nnz) {
     if (rows < 0 || cols < 1 || !a_indptr || !b_indptr || !nnz) return nullptr;
     if ((a_indptr[rows] > 0 && (!a_indices || !a_data)) || cols > (int64_t)2147483647) return nullptr;
+    try {
     // accumulators: 12 bytes per column and thread, at most ~512 MB in all
     int t = pick_threads(threads, std::max<int64_t>(1, rows / 64));
     t = (int)std::max<int64_t>(1, std::min<int64_t>(t, ((int64_t)512 << 20) / (12 * cols)));
     Team team(t);
-    auto *out = new Product;
+    std::unique_ptr<Product> out(new Product);  // (released to the caller only when the product is complete)
     out->rows = rows;
     out->row_nnz.assign((size_t)rows, 0);
     out->indices.resize((size_t)t);
@@ -310,11 +353,14 @@ extern "C" void *tdgl_host_spgemm(int64_t rows, int64_t cols, const int32_t *a_i
     int64_t total = 0;
     for (const auto &v : out->indices) total += (int64_t)v.size();
     *nnz = total;
-    return out;
+    return out.release();
+    } catch (...) {
+        return nullptr;
+    }
 }
 
 extern "C" int tdgl_host_spgemm_take(void *handle, int64_t *indptr, int32_t *indices, double *data) {
-    auto *p = static_cast<Product *>(handle);
+    std::unique_ptr<Product> p(static_cast<Product *>(handle));
     if (!p) return -1;
     if (indptr) {
         indptr[0] = 0;
@@ -326,6 +372,5 @@ extern "C" int tdgl_host_spgemm_take(void *handle, int64_t *indptr, int32_t *ind
             at += (int64_t)p->indices[t].size();
         }
     }
-    delete p;
     return 0;
 }

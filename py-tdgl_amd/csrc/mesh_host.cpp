@@ -483,15 +483,17 @@ struct Triangulator {
 
 }  // namespace
 
-extern "C" int tdgl_host_delaunay(int64_t n, const double *xy, int64_t *triangles, int64_t *n_triangles) {
+extern "C" int tdgl_host_delaunay(int64_t n, const double *xy, int64_t *triangles, int64_t *n_triangles) try {
     if (!xy || !triangles || !n_triangles || n < 3 || n > (int64_t)300000000) return TDGL_MESH_ERR_ARG;
     Triangulator t;
     t.xy = xy;
     t.n = (int)n;
     return t.run(triangles, n_triangles);
+} catch (...) {  // std::bad_alloc: no exception crosses the C boundary
+    return TDGL_MESH_ERR_RESOURCES;
 }
 
-extern "C" int tdgl_host_is_delaunay(int64_t n, const double *xy, int64_t n_triangles, const int64_t *triangles) {
+extern "C" int tdgl_host_is_delaunay(int64_t n, const double *xy, int64_t n_triangles, const int64_t *triangles) try {
     if (!xy || !triangles || n < 3 || n_triangles < 1) return TDGL_MESH_ERR_ARG;
     // edge -> (triangle, opposite vertex) through a sort of directed edges
     struct Rec {
@@ -518,11 +520,13 @@ extern "C" int tdgl_host_is_delaunay(int64_t n, const double *xy, int64_t n_tria
         if (s > 0.0) return 0;
     }
     return 1;
+} catch (...) {  // std::bad_alloc: no exception crosses the C boundary
+    return TDGL_MESH_ERR_RESOURCES;
 }
 
 extern "C" int tdgl_host_dual_mesh(int64_t n, const double *xy, int64_t nt, const int64_t *tri, int64_t *n_edges, int64_t *edges,
                                    uint8_t *is_boundary, int64_t *tri_edge, double *centers, double *directions,
-                                   double *edge_lengths, double *cc, double *dual, double *areas, uint8_t *suspicious) {
+                                   double *edge_lengths, double *cc, double *dual, double *areas, uint8_t *suspicious) try {
     if (!xy || !tri || !n_edges || !edges || !is_boundary || !tri_edge || !centers || !directions || !edge_lengths || !cc || !dual ||
         !areas || !suspicious || n < 3 || nt < 1)
         return TDGL_MESH_ERR_ARG;
@@ -627,4 +631,6 @@ extern "C" int tdgl_host_dual_mesh(int64_t n, const double *xy, int64_t nt, cons
         for (int64_t t = 0; t < nt; ++t) areas[tri[3 * t + iq]] += contrib[(size_t)t];
     }
     return TDGL_MESH_OK;
+} catch (...) {  // std::bad_alloc: no exception crosses the C boundary
+    return TDGL_MESH_ERR_RESOURCES;
 }

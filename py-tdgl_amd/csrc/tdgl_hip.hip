@@ -74,7 +74,7 @@ static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indp
     HIP_TRY(ctx, pat.slice_off.upload(off));
     HIP_TRY(ctx, pat.cols.upload(cols));
     pat.use16 = false;
-    if (want16 && !getenv("TDGL_NO_INDEX16")) {  // (the environment switch is for A/B measurements)
+    if (want16) {
         std::vector<int16_t> d16(pat.n_slots);
         bool fits = true;
         for (int sl = 0; sl < pat.n_slices && fits; ++sl)
@@ -95,7 +95,7 @@ static int build_sell_pattern(tdgl_ctx *ctx, int64_t n_rows, const int32_t *indp
         }
     }
     pat.use_off16 = false;
-    if (want_off16 && !getenv("TDGL_NO_INDEX16")) {
+    if (want_off16) {
         std::vector<uint16_t> o16(std::max<int64_t>(pat.n_slots, 1), 0);
         std::vector<int32_t> sbase(std::max<int32_t>(pat.n_slices, 1), 0);
         bool fits = true;
@@ -166,7 +166,6 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_pack) (void)hipEventDestroy(ctx->ev_pack);
     if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
-    if (ctx->pcg_graph) (void)hipGraphExecDestroy(ctx->pcg_graph);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     for (auto &pr : ctx->prof_pending) {
         (void)hipEventDestroy(pr.first);
@@ -356,20 +355,13 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     HIP_TRY(ctx, ctx->jn.alloc(ctx->m_pad));
     HIP_TRY(ctx, ctx->d_status.alloc(1));
     // The status block is published into device memory and copied to this pinned block at every host
-    // synchronisation (a ~4 us blit kernel, twice per step).  TDGL_STATUS_MAPPED=1 lets the publishing
-    // workgroup store straight into the (mapped) host block instead: nothing at >= 250k sites, +10 % at
-    // 5.8k sites (profiles/AB_r02s.jsonl) -- not the default: one of ~40 runs with it ended in a core
-    // dump that could neither be reproduced nor explained.
-    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(StepStatus), hipHostMallocMapped));
+    // synchronisation.
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_status), sizeof(StepStatus)));
     memset(ctx->h_status, 0, sizeof(StepStatus));
-    ctx->status_copy = getenv("TDGL_STATUS_MAPPED") == nullptr;
+    // (the three environment switches of the library: what the test-suite needs to reach a code path -- DESIGN.md section 5)
     ctx->run_ahead_disabled = getenv("TDGL_NO_RUN_AHEAD") != nullptr;
     if (const char *e = getenv("TDGL_PCG_PREDICT")) ctx->pcg_predict_from_guess = strcmp(e, "last") != 0;
-    if (ctx->status_copy) {
-        ctx->status_dev = ctx->d_status.p;
-    } else {
-        HIP_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->status_dev), ctx->h_status, 0));
-    }
+    ctx->status_dev = ctx->d_status.p;
     HIP_TRY(ctx, ctx->scal.alloc(S_COUNT));
     HIP_TRY(ctx, ctx->d_ctl.alloc(1));
     HIP_TRY(ctx, ctx->d_rec.alloc(RA_BATCH_MAX));
@@ -381,7 +373,7 @@ static int create_impl(tdgl_ctx *ctx, const tdgl_mesh_desc *d) {
     {
         const int64_t tiles = (ctx->n_own + BLOCK - 1) / BLOCK;
         ctx->npart = (int)std::min<int64_t>(NB, std::max<int64_t>(1, (tiles + XCDS - 1) / XCDS) * XCDS);
-        if (ctx->n_own < ctx->n || getenv("TDGL_FULL_PARTIALS")) ctx->npart = NB;  // (environment switch: A/B measurements)
+        if (ctx->n_own < ctx->n) ctx->npart = NB;
     }
     HIP_TRY(ctx, ctx->psi_dmax_part.alloc(ctx->psi_blocks));
     HIP_TRY(ctx, ctx->psi_fail_part.alloc(ctx->psi_blocks));
@@ -543,11 +535,8 @@ static void launch_ra_laplacian(tdgl_ctx *ctx) {
 // workgroups of the projection guess's dot-product pass (k_multi_dot): one per CU -- every workgroup ends with
 // a reduction of 2 K + 2 double-double sums, and the status kernel (ONE workgroup, on the step's critical
 // path) adds that many partials per sum; four waves per CU with 13 16-byte loads per lane in flight keep
-// the stream busy.  (TDGL_GUESS_GRID: A/B switch.)
-static inline int guess_grid(const tdgl_ctx *ctx) {
-    static const char *env = getenv("TDGL_GUESS_GRID");
-    return std::min(ctx->npart, env ? std::max(8, atoi(env) / 8 * 8) : 256);
-}
+// the stream busy.
+static inline int guess_grid(const tdgl_ctx *ctx) { return std::min(ctx->npart, 256); }
 // one process per GPU with at most G_RANK_STRIDE ranks: the ranks' double-double totals are gathered exactly
 static inline bool guess_rank_totals(const tdgl_ctx *ctx) {
     static const bool off = getenv("TDGL_GUESS_NO_GATHER") != nullptr;  // (tests: the path of more than 16 ranks)
@@ -760,6 +749,7 @@ extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
     TDGL_TRY(apply_mu_boundary(ctx, mu_boundary));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->tab_mu_host.empty() && ctx->nb > 0) ctx->tab_mu_host.assign(mu_boundary, mu_boundary + ctx->nb);
+    ctx->tab_mu_dev_synced = !ctx->tab_mu_host.empty();  // (the device holds exactly this array now)
     return TDGL_OK;
 }
 
@@ -786,6 +776,7 @@ extern "C" int tdgl_set_mu_boundary_table(tdgl_ctx *ctx, int32_t n_nodes, const 
     CTX_GUARD(ctx);
     ctx->tab_mu_t.clear();
     ctx->tab_mu_host.clear();
+    ctx->tab_mu_dev_synced = false;
     if (n_nodes == 0) return TDGL_OK;  // off
     if (n_nodes < 1 || n_groups < 1 || !times || !group_ptr || !group_pos || !density || !table_times_ok(times, n_nodes))
         TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_mu_boundary_table: bad table (times must increase strictly)");
@@ -861,6 +852,7 @@ static int apply_time_tables(tdgl_ctx *ctx) {
             // (the copy of tab_mu_host is asynchronous: wait before the host array can change again)
             TDGL_TRY(apply_mu_boundary(ctx, ctx->tab_mu_host.data()));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->tab_mu_dev_synced = true;
         }
     }
     if (!ctx->tab_eps_t.empty()) {
@@ -1088,8 +1080,7 @@ extern "C" int tdgl_psi_update(tdgl_ctx *ctx, const double *psi, const double *m
     launch_psi_update(ctx, s.c0.p, s.r0.p, lap.p, dt, pnew.p, s.r1.p);
     publish_status(ctx);
     HIP_TRY(ctx, hipGetLastError());
-    if (ctx->status_copy)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status.p, sizeof(StepStatus), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status.p, sizeof(StepStatus), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *ok = ctx->h_status->fail_flag ? 0 : 1;
     TDGL_TRY(download_sites(ctx, pnew.p, reinterpret_cast<double2 *>(psi_out)));

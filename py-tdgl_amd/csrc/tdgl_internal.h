@@ -259,6 +259,7 @@ struct tdgl_ctx {
     std::vector<double> tab_mu_t, tab_mu_dens;       // nodes; densities [n_groups x n_nodes]
     std::vector<int32_t> tab_mu_ptr, tab_mu_pos;     // groups of boundary-edge positions (CSR-like)
     std::vector<double> tab_mu_last, tab_mu_host;    // last densities applied; host copy of mu_boundary
+    bool tab_mu_dev_synced = false;                  // b_mu on the device holds tab_mu_host at the positions no table covers
     // the same table on the device, for the run-ahead loop (k_ra_mu_table evaluates it at the device's own time)
     tdgl::DevBuf<double> d_tab_mu_t, d_tab_mu_dens;
     tdgl::DevBuf<int32_t> d_tab_mu_group;            // [nb]: group of a boundary position, -1 = not tabulated
@@ -298,12 +299,7 @@ struct tdgl_ctx {
     tdgl::DevBuf<int32_t> fusedR_base;
     bool f32_ready = false;               // fp32 copies are current
     bool coarse32_ready = false;          // ... of the intermediate-level operators
-    // two consecutive PCG iterations (odd, even) captured as a hipGraph: replayed while the
-    // solve is launch bound (small meshes); re-captured when anything it bakes in changes
-    hipGraphExec_t pcg_graph = nullptr;
-    int64_t pcg_graph_epoch = -1, pcg_epoch = 0;
-    int pcg_graph_mode = -1;              // (f32 | coarse32 << 1) it was captured with
-    bool use_graph = true;
+    int64_t pcg_epoch = 0;                // bumped whenever an operator of the solve is replaced
     int64_t f32_fallbacks = 0;            // solves that had to be finished with the fp64 operators
     tdgl::DevBuf<double> coarse_pinv;
     int64_t n_coarsest = 0;
@@ -362,11 +358,6 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> scal;            // tdgl::Scal (numbers the host reads)
     tdgl::DevBuf<double> mu_prev, mu_prev2;  // mu^{n-1}, mu^{n-2} for the extrapolated initial guess
     double prev_dt = 0.0, prev_dt2 = 0.0;    // dt of the steps that produced mu / mu_prev (0: no history)
-    // lazy CG update (poisson.inc): the update of the previous iteration still to be applied while
-    // the current iteration's V-cycle is being queued; xr_carried = some launch of the coarse chain
-    // took it along
-    bool xr_active = false, xr_carried = false;
-    tdgl::XrArgs xr{};
     tdgl_poisson_options popt{1e-10, 500, 2, 0, 1, 1, 0.1, 3, 1, 2, 0, 0};
     // projection guess (popt.extrapolate == 3): window of previous solutions x_j and their images
     // y_j = A x_j (= b_j - r_j with the final residual of the CG recurrence), oldest first;
@@ -407,9 +398,8 @@ struct tdgl_ctx {
     int psi_blocks = 0;                    // its grid
     bool psi_status_pending = false;       // not yet reduced into d_status
     tdgl::DevBuf<tdgl::StepStatus> d_status;
-    tdgl::StepStatus *h_status = nullptr;  // pinned, mapped into the device
-    tdgl::StepStatus *status_dev = nullptr;  // what the kernels write: h_status's device view (or d_status)
-    bool status_copy = false;
+    tdgl::StepStatus *h_status = nullptr;  // pinned: d_status is copied here at every host synchronisation
+    tdgl::StepStatus *status_dev = nullptr;  // what the kernels write (= d_status.p)
     std::vector<int32_t> probes;           // internal site ids
     tdgl::DevBuf<int32_t> d_probes;
     tdgl::DevBuf<double> d_probe_out;      // ring buffer [PROBE_RING_STEPS][2 * n_probe]: mu | theta per step

@@ -2,9 +2,10 @@
 helpers -- Delaunay triangulation, the Voronoi dual mesh, and the two loops of the AMG set-up (Lanczos estimate of
 rho(D^-1 A), MIS(2) aggregation) -- in plain C++ (no HIP, no GPU needed).
 
-Like the HIP library it is built by ``__graft_entry__.build()`` and there is no silent substitute:
-`delaunay` / `dual_mesh` raise if the library is missing.  (SciPy's Qhull remains available by name,
-``meshgen.triangulate(points, backend="qhull")``, and is what the tests compare against.)
+It is built by ``__graft_entry__.build()`` (g++ only).  `delaunay` / `dual_mesh` raise if the library is
+missing; their callers `meshgen.triangulate` and `Mesh.from_triangulation` ask `available()` first and, on a host
+where it was never built, warn once and use the constructions it replaced (SciPy's Qhull, the NumPy dual mesh --
+the latter bit-identical).  Nothing of the time loop lives here: the HIP library has no substitute.
 """
 
 import ctypes as C
@@ -15,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TDGL_MESH_LIB") or os.path.join(_HERE, "lib", "libtdgl_mesh.so")
 
-OK, ERR_ARG, ERR_DEGENERATE, ERR_SKIPPED, ERR_INDEX = 0, -1, -2, -3, -4
+OK, ERR_ARG, ERR_DEGENERATE, ERR_SKIPPED, ERR_INDEX, ERR_RESOURCES = 0, -1, -2, -3, -4, -5
 
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -39,6 +40,24 @@ _lib = None
 
 class MeshLibraryError(RuntimeError):
     pass
+
+
+_warned = False
+
+
+def available() -> bool:
+    """Whether libtdgl_mesh.so can be loaded; warns once when it cannot."""
+    global _warned
+    if _lib is not None or os.path.exists(LIB_PATH):
+        return True
+    if not _warned:
+        import warnings
+
+        warnings.warn(f"{LIB_PATH} not found (build it with `python -c 'import __graft_entry__ as g; g.build()'`): "
+                      "mesh set-up falls back to SciPy Qhull / NumPy, several times slower", RuntimeWarning,
+                      stacklevel=3)
+        _warned = True
+    return False
 
 
 def load():
@@ -74,6 +93,8 @@ def delaunay(points):
     rc = load().tdgl_host_delaunay(n, pts.ctypes.data_as(_f64p), out.ctypes.data_as(_i64p), C.byref(nt))
     if rc == ERR_ARG:
         raise ValueError("tdgl_host_delaunay: non-finite coordinates")
+    if rc == ERR_RESOURCES:
+        raise MemoryError("tdgl_host_delaunay: out of memory")
     return rc, out[: 3 * nt.value].reshape(-1, 3).copy()
 
 
@@ -110,6 +131,8 @@ def dual_mesh(points, triangles):
         dual.ctypes.data_as(_f64p), areas.ctypes.data_as(_f64p), suspicious.ctypes.data_as(_u8p))
     if rc == ERR_INDEX:
         raise IndexError("a triangle refers to a site that does not exist")
+    if rc == ERR_RESOURCES:
+        raise MemoryError("tdgl_host_dual_mesh: out of memory")
     if rc != OK:
         raise ValueError(f"tdgl_host_dual_mesh: status {rc}")
     m = m.value
@@ -139,6 +162,8 @@ def lanczos(A, dinv, v0, iters, threads=0):
     rc = load().tdgl_host_lanczos(n, indptr.ctypes.data_as(_i32p), indices.ctypes.data_as(_i32p), data.ctypes.data_as(_f64p),
                                   dinv.ctypes.data_as(_f64p), int(iters), v0.ctypes.data_as(_f64p), int(threads),
                                   alpha.ctypes.data_as(_f64p), beta.ctypes.data_as(_f64p), C.byref(steps), C.byref(gersh))
+    if rc == ERR_RESOURCES:
+        raise MemoryError("tdgl_host_lanczos: out of memory or threads")
     if rc != 0:
         raise ValueError(f"tdgl_host_lanczos: status {rc}")
     return alpha[: steps.value], beta[: steps.value], gersh.value
@@ -158,6 +183,8 @@ def mis2_aggregate(S, priority, threads=0):
                                          prio.ctypes.data_as(_i64p), int(threads), agg.ctypes.data_as(_i64p), C.byref(n_agg))
     if rc == -2:
         raise RuntimeError("MIS(2) did not terminate")
+    if rc == ERR_RESOURCES:
+        raise MemoryError("tdgl_host_mis2_aggregate: out of memory or threads")
     if rc != 0:
         raise ValueError(f"tdgl_host_mis2_aggregate: status {rc}")
     return agg, int(n_agg.value)
@@ -187,7 +214,7 @@ def spgemm(A, B, threads=0):
                              bp.ctypes.data_as(_i32p), bi.ctypes.data_as(_i32p), bd.ctypes.data_as(_f64p), int(threads),
                              C.byref(nnz))
     if not h:
-        raise ValueError("tdgl_host_spgemm: bad arguments")
+        raise MemoryError("tdgl_host_spgemm: bad arguments, or out of memory / threads")
     indptr = np.empty(rows + 1, dtype=np.int64)
     indices = np.empty(nnz.value, dtype=np.int32)
     data = np.empty(nnz.value, dtype=np.float64)

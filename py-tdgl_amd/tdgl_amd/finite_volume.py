@@ -254,7 +254,10 @@ class Mesh:
         if backend == "native":  # tdgl_host_dual_mesh (include/tdgl_host_mesh.h): the same numbers, bit for bit, 5x sooner
             from . import _mesh_lib
 
-            d = _mesh_lib.dual_mesh(sites, elements)
+            if _mesh_lib.available():
+                d = _mesh_lib.dual_mesh(sites, elements)
+            else:  # host-only set-up code: the NumPy construction gives the same numbers, bit for bit
+                d = _dual_mesh_numpy(sites, elements)
         elif backend == "numpy":
             d = _dual_mesh_numpy(sites, elements)
         else:

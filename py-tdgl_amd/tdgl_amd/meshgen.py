@@ -56,18 +56,33 @@ def triangulate(points: np.ndarray, backend: str = "native") -> np.ndarray:
     ``backend="native"``: `tdgl_host_delaunay` (include/tdgl_host_mesh.h; sweep-hull insertion with exact
     predicates, counter-clockwise triangles) -- 0.9 s per million points where Qhull takes 7.7 s, the same
     set of triangles for points in general position.  ``"qhull"``: `scipy.spatial.Delaunay`.  A point cloud
-    with coinciding points (the native code leaves the repeats out and says so) goes to Qhull as before."""
+    with coinciding points (the native code leaves the repeats out and says so), one it calls degenerate
+    (collinear, or coordinates so large / small that squared distances leave the fp64 range) goes to Qhull;
+    ``ValueError`` if Qhull cannot triangulate it either."""
     if backend == "native":
         from . import _mesh_lib
 
-        status, tri = _mesh_lib.delaunay(points)
-        if status == _mesh_lib.OK:
-            return tri
-        if status == _mesh_lib.ERR_DEGENERATE:
-            raise ValueError("triangulate: all points are collinear")
+        if _mesh_lib.available():
+            status, tri = _mesh_lib.delaunay(points)
+            if status == _mesh_lib.ERR_DEGENERATE and len(points) >= 3:
+                # all collinear -- or squared distances that overflow / underflow, which the native predicates
+                # report the same way: once more in the unit box (a shift and a power-of-two scale)
+                pts = np.asarray(points, dtype=float)
+                lo = pts.min(axis=0)
+                extent = float((pts.max(axis=0) - lo).max())
+                if np.isfinite(extent) and extent > 0:
+                    points = (pts - lo) * 2.0 ** -np.ceil(np.log2(extent))
+                    status, tri = _mesh_lib.delaunay(points)
+            if status == _mesh_lib.OK:
+                return tri
+        # ERR_SKIPPED (coinciding points), still ERR_DEGENERATE, or no library: Qhull decides
     elif backend != "qhull":
         raise ValueError(f"unknown backend {backend!r}")
-    return np.asarray(Delaunay(points).simplices, dtype=np.int64)
+    try:
+        tri = Delaunay(points).simplices
+    except Exception as exc:  # QhullError: flat input
+        raise ValueError(f"triangulate: the points cannot be triangulated ({str(exc).splitlines()[0]})") from exc
+    return np.asarray(tri, dtype=np.int64)
 
 
 def rectangle_mesh_points(
@@ -130,12 +145,13 @@ def _segment_distance(pts, a, b, within=None):
     return out
 
 
-def polygon_mesh(film, holes=(), max_edge_length=1.0, seed=0, max_rounds=12):
+def polygon_mesh(film, holes=(), max_edge_length=1.0, seed=0, max_rounds=12, backend="native"):
     """Boundary-conforming Delaunay mesh of ``film`` minus ``holes`` (closed or open ``(k, 2)``
-    vertex arrays) with no edge longer than ``max_edge_length``.  Returns ``(points, triangles)``."""
+    vertex arrays) with no edge longer than ``max_edge_length``.  Returns ``(points, triangles)``.
+    ``backend``: the triangulator (`triangulate`)."""
     pitch = 0.65 * float(max_edge_length)
     for _ in range(6):
-        pts, tri = _polygon_mesh_at_pitch(film, holes, pitch, seed, max_rounds)
+        pts, tri = _polygon_mesh_at_pitch(film, holes, pitch, seed, max_rounds, backend)
         e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
         longest = np.linalg.norm(pts[e[:, 0]] - pts[e[:, 1]], axis=1).max()
         if longest <= max_edge_length:
@@ -144,7 +160,7 @@ def polygon_mesh(film, holes=(), max_edge_length=1.0, seed=0, max_rounds=12):
     raise RuntimeError("polygon_mesh: could not satisfy max_edge_length")  # pragma: no cover
 
 
-def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
+def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds, backend="native"):
     h = float(h)
     loops = []
     for poly in [film] + list(holes):
@@ -178,7 +194,7 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds):
     for _ in range(max_rounds):
         nb = [len(b) for b in bloops]
         pts = np.concatenate(bloops + [lattice])
-        tri = triangulate(pts)
+        tri = triangulate(pts, backend)
         cent = pts[tri].mean(axis=1)
         inside = _points_in_poly(loops[0], cent)
         for hole in loops[1:]:

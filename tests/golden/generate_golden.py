@@ -1,6 +1,6 @@
 """Generate the golden fixtures by running the REFERENCE itself (build container only).
 
-    python tests/golden/generate_golden.py
+    python tests/golden/generate_golden.py [--out DIR] [--quick]
 
 imports py-tdgl v0.8.3 from `/root/reference` (see `_reference_shim.py`), drives its own
 `Mesh.from_triangulation`, `MeshOperators`, `TDGLSolver.solve_for_psi_squared`,
@@ -32,7 +32,22 @@ from tdgl.solver.options import SolverOptions, SparseSolver  # noqa: E402
 from tdgl.solver.runner import Runner  # noqa: E402
 from tdgl.solver.solver import TDGLSolver  # noqa: E402
 
-from tdgl_amd.meshgen import hex_jitter_points, triangulate  # noqa: E402
+from scipy.spatial import Delaunay  # noqa: E402
+
+from tdgl_amd.meshgen import hex_jitter_points  # noqa: E402
+
+# Where the .npz files go: next to this script unless --out DIR is given (the regeneration test in
+# tests/test_oracle_golden.py writes into a scratch directory and compares with the committed files).
+OUT_DIR = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else HERE
+
+
+def triangulate(pts):
+    """Fixture inputs must not depend on product code that can change: the triangulation every fixture mesh is
+    built on is SciPy's Qhull Delaunay (what SURVEY.md Appendix B prescribes), never the product's own
+    triangulator -- its element order and orientation differ, and with them the last bits of the reference's
+    Voronoi areas and every chaotic trajectory."""
+    return np.asarray(Delaunay(pts).simplices, dtype=np.int64)
+
 
 U_DEFAULT, GAMMA_DEFAULT = 5.79, 10.0
 
@@ -263,7 +278,7 @@ def coo(mat, prefix):
 
 
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays")
 
@@ -397,7 +412,7 @@ def main():
     film = np.array([(-15, -2), (-5, -2), (-5, -5), (5, -5), (5, -2), (15, -2), (15, 2), (5, 2), (5, 5),
                      (-5, 5), (-5, 2), (-15, 2)], dtype=float)
     holes = [circle(1.5, center=(-2.5, 0), points=40), circle(1.0, center=(2.5, 1.0), points=30)]
-    ppts, ptri = polygon_mesh(film, holes, max_edge_length=0.8)
+    ppts, ptri = polygon_mesh(film, holes, max_edge_length=0.8, backend="qhull")  # see triangulate() above
     save("mesh_polygon", film=film, hole0=holes[0], hole1=holes[1],
          **mesh_arrays(RefMesh.from_triangulation(ppts, ptri)))
     if "--meshes-only" in sys.argv:
@@ -455,6 +470,8 @@ def main():
     arrays["ok"] = np.array(ok)
     print("psi_update ok flags:", ok)
     save("psi_update_small", **arrays)
+    if "--quick" in sys.argv:  # meshes + operators + single psi updates (tests/test_oracle_golden.py regenerates these)
+        return
 
     # ---- (4) trajectories ------------------------------------------------------------
     # (4a) BASELINE config 1: ~5k sites, zero field, 500 steps (adaptive, reference defaults

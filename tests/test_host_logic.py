@@ -1153,8 +1153,12 @@ def test_native_delaunay_on_degenerate_input():
     assert len(np.unique(triangulate(pts))) == 100
     status, tri = _mesh_lib.delaunay(np.column_stack([np.arange(50.0), 2 * np.arange(50.0)]))
     assert status == _mesh_lib.ERR_DEGENERATE
-    with pytest.raises(ValueError, match="collinear"):
+    with pytest.raises(ValueError, match="cannot be triangulated"):
         triangulate(np.column_stack([np.arange(50.0), 2 * np.arange(50.0)]))
+    # coordinates whose squared distances leave the fp64 range: the native predicates call them degenerate, Qhull decides
+    cloud = np.random.default_rng(5).random((500, 2))
+    for scale in (1e150, 1e-160):
+        assert len(triangulate(cloud * scale)) == len(triangulate(cloud))
     with pytest.raises(ValueError, match="non-finite"):
         _mesh_lib.delaunay(np.array([[0.0, 0.0], [1.0, 0.0], [0.0, np.nan]]))
     # is_delaunay is a real check: flip one diagonal of a jittered cloud
