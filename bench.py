@@ -454,6 +454,9 @@ def main():
         ctx.profile_enable(False)
         work = ctx.step_stats()
         ev_over = ctx.profile_event_overhead(50)  # (after the timed region)
+        # K1 once more, after the timed region: ONE event pair around 16 back-to-back launches on the state the timed
+        # steps ended on -- the pair's own ~4.5 us is amortised over 16 launches instead of sitting in every sample
+        k1_burst_ms = ctx.time_kernel(1, 16) if not use_dd else None
         comm = ctx.comm_stats()
         # parity_vs_oracle, direct form: the fields the timed steps themselves ended on
         end_state = ctx.get_state() if (want_cpu_state and not args.no_parity and args.steps <= PARITY_STEPS) else None
@@ -465,7 +468,7 @@ def main():
             elapsed = float(tmax.item())
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
-            k1=(launches, k1_ms), axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
+            k1=(launches, k1_ms), k1_burst_ms=k1_burst_ms, axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
             end_state=end_state, work=work, setup=setup, windows={},
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats(), batch_prediction=ctx.pcg_prediction_stats()),
             overlap=ctx.comm_overlap() if use_dd else None,
@@ -598,11 +601,22 @@ def main():
         avg = k1_ms / max(launches, 1)
         achieved = ab["K1_psi_laplacian_spmv"] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
         table, src = pmc_traffic(r.name) if not use_dd else ({}, None)
+        nbytes = ab["K1_psi_laplacian_spmv"]
+        net = avg - r.ev_over  # the same samples without the reading of an empty event pair
+        burst = getattr(r, "k1_burst_ms", None)
         return dict(
             bound="hbm",
             kernel="k_psi_laplacian<true> (SELL-64 covariant-Laplacian SpMV fused with the Poisson right-hand side)"
                    + (f"; rank 0's {r.n_loc} owned rows" if use_dd else ""),
             achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+            # `frac` is the contract's figure: raw HIP-event readings of every launch in the timed region, each with
+            # the event pair's own overhead inside.  frac_net subtracts that overhead (measured after the region);
+            # frac_burst is one pair around 16 back-to-back launches after the region (overhead amortised; repeated
+            # launches may find part of the operator in the Infinity Cache, so it is an upper bracket).  The kernel
+            # trace under profiles/ (rocprofv3 dispatch durations, no events) should fall between frac_net and frac_burst.
+            frac_net=round(nbytes / (net * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if net > 0 else None,
+            frac_burst=None if not burst else round(nbytes / (burst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            avg_launch_ms_burst=None if not burst else round(burst, 5),
             traffic=traffic_of(table, "void tdgl::k_psi_laplacian<true"),
             traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
             algorithmic_bytes_per_launch=ab["K1_psi_laplacian_spmv"], avg_launch_ms=round(avg, 5), launches=launches,
@@ -661,6 +675,13 @@ def main():
                    "one launch per PCG iteration, the largest single share of the run time)",
             achieved=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(axp_alg / (axp_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # the canonical bytes above are what an unfused fp64 / int32 kernel would move; this kernel's operator
+            # stream is narrower (16-bit column offsets), so what it PHYSICALLY moves (PMC counters) is less:
+            # frac_traffic = PMC bytes / time, frac_traffic_net the same without the event pair's own overhead
+            frac_traffic=(lambda t: None if not t else round(t / (axp_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))(
+                traffic_of(table, "void tdgl::k_sell_axp")),
+            frac_traffic_net=(lambda t: None if (not t or axp_avg_ms <= main_run.ev_over) else round(
+                t / ((axp_avg_ms - main_run.ev_over) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))(traffic_of(table, "void tdgl::k_sell_axp")),
             traffic=traffic_of(table, "void tdgl::k_sell_axp"),
             traffic_source=None if src is None else f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, gfx950 correction), {src}",
             algorithmic_bytes_per_launch=int(axp_alg), avg_launch_ms=round(axp_avg_ms, 5), launches=main_run.axp[0],

@@ -79,6 +79,15 @@ typedef struct {
     const int32_t *R_indptr;  const int32_t *R_indices;  const double *R_data; /* n_coarse x n */
     int64_t n_cols;       /* level 0 in distributed mode: columns of A / rows of P = owned +
                              ghost sites (A is n x n_cols, P is n_cols x n_coarse); 0 = n    */
+    /* Two distributed levels (tdgl_set_deep_halo_plan below); all 0 otherwise.
+     * Level 0: A has a_rows >= n rows (owned + first ghost layer: z is formed there too), P has p_rows >= a_rows rows
+     * (+ second ghost layer: where x is formed), n_cols >= p_rows is the whole ghost zone (where r is received);
+     * A's columns are < p_rows, R is not used (NULL allowed: the fused restriction replaces it).
+     * Level 1 (explicit_only = 1): no A / P / R at all -- the level exists through its explicit operators
+     * (tdgl_poisson_set_collapsed_level: M [n_coarse x <= n], tdgl_poisson_set_collapsed_up: W [n x n_cols],
+     * V [n x n_coarse]); n = the level-1 rows this rank forms x1 on, n_cols = the level-1 entries it forms b1 on. */
+    int64_t a_rows, p_rows;
+    int32_t explicit_only;
 } tdgl_amg_level;
 
 /* Adaptive time-step controller = SolverOptions fields read by the step
@@ -342,6 +351,28 @@ typedef struct {
                                         neighbour k fills sites n_owned + recv_ptr[k] ...  */
 } tdgl_halo_plan;
 int tdgl_set_halo_plan(tdgl_ctx *ctx, const tdgl_halo_plan *plan);
+
+/* Two distributed AMG levels with ONE vector exchange per PCG iteration (host: tdgl_amd/partition.py DeepPlanner).
+ * The aggregates of level 0 lie inside ranks, so level 1 has owners; every rank forms redundantly what it would
+ * otherwise receive (x1 on the level-1 rows its prolongation reads, b1 on the columns W1 reads there, z on its first
+ * ghost layer) from the residual r on a DEEP ghost zone -- the closure of those stencils, 5-9 % of the owned rows at
+ * 500k rows per rank.  Per iteration a rank then communicates three times: this exchange of r, the sum of the
+ * partial level-2 right-hand sides, the CG's dot products (before: the ghosts of r and of z, a level-1-sized sum, the
+ * dot products).  Local vector layout: [owned | ghost layer 1 (tdgl_halo_plan's ghosts) | layer 2 | deeper], n_ext
+ * entries; neighbour k sends the owned entries send_idx[send_ptr[k] ...] and its values land in the ghost entries
+ * recv_idx[recv_ptr[k] ...] (any order: an unpack kernel scatters them); a neighbour may have an empty send or
+ * receive list.  Call after tdgl_set_halo_plan and before tdgl_poisson_set_hierarchy, whose level 0 must then
+ * carry a_rows / p_rows / n_cols = n_ext and whose level 1 must be explicit_only. */
+typedef struct {
+    int64_t n_ext;
+    int32_t n_neighbors;
+    const int32_t *neighbor_ranks;   /* [n_neighbors] */
+    const int32_t *send_ptr;         /* [n_neighbors + 1] */
+    const int32_t *send_idx;         /* owned local ids */
+    const int32_t *recv_ptr;         /* [n_neighbors + 1] */
+    const int32_t *recv_idx;         /* ghost local ids in [n_owned, n_ext) */
+} tdgl_deep_halo_plan;
+int tdgl_set_deep_halo_plan(tdgl_ctx *ctx, const tdgl_deep_halo_plan *plan);
 /* RCCL transport (xGMI): rank 0 makes the 128-byte id, the host layer broadcasts it, every rank
  * calls tdgl_comm_init_rccl.  Collectives run on the context's stream. */
 int tdgl_comm_unique_id(char *out128);

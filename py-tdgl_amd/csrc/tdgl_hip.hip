@@ -158,6 +158,8 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
     if (ctx->h_sendbuf) (void)hipHostFree(ctx->h_sendbuf);
     if (ctx->h_recvbuf) (void)hipHostFree(ctx->h_recvbuf);
+    if (ctx->h_deep_send) (void)hipHostFree(ctx->h_deep_send);
+    if (ctx->h_deep_recv) (void)hipHostFree(ctx->h_deep_recv);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->h_ctl) (void)hipHostFree(ctx->h_ctl);
     if (ctx->h_rec) (void)hipHostFree(ctx->h_rec);

@@ -102,6 +102,8 @@ struct Csr {
 // dependent gather chain per wave, so they use CSR with several lanes per row instead.
 struct AmgLevel {
     int64_t n = 0, n_pad = 0, n_coarse = 0;
+    int64_t n_cols = 0;              // entries of this level's right-hand side / iterate vectors (>= n: ghost entries)
+    bool explicit_only = false;      // a distributed level 1: no A / P / R, only M, Wup, Vneg
     double rho = 2.0;
     SellF64 A;                       // level 0
     Csr Ac;                          // levels >= 1
@@ -226,6 +228,14 @@ struct tdgl_ctx {
     int64_t stat_halos = 0, stat_halo_bytes = 0, stat_allreduces = 0, stat_allreduce_bytes = 0;
     double *pend_v = nullptr; // exchange started by comm_halo_start, completed by comm_halo_wait
     int pend_width = 0;
+    // two distributed AMG levels (tdgl_set_deep_halo_plan): the exchange of r on the whole ghost zone
+    bool deep = false;
+    int64_t n_ext = 0;        // owned + every ghost layer (length of the PCG's level-0 vectors)
+    std::vector<int32_t> deep_nbrs, deep_send_ptr, deep_recv_ptr;
+    tdgl::DevBuf<int32_t> d_deep_send_idx, d_deep_recv_idx;
+    tdgl::DevBuf<double> d_deep_sendbuf, d_deep_recvbuf;
+    double *h_deep_send = nullptr, *h_deep_recv = nullptr;  // pinned (callback transport)
+    int64_t stat_deep_halos = 0;
 
     // permutations (host)
     std::vector<int32_t> perm, iperm;            // internal -> reference site, and inverse

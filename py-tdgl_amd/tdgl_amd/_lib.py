@@ -63,6 +63,21 @@ class AmgLevel(C.Structure):
         ("R_indices", c_i32p),
         ("R_data", c_f64p),
         ("n_cols", C.c_int64),
+        ("a_rows", C.c_int64),
+        ("p_rows", C.c_int64),
+        ("explicit_only", C.c_int32),
+    ]
+
+
+class DeepHaloPlan(C.Structure):
+    _fields_ = [
+        ("n_ext", C.c_int64),
+        ("n_neighbors", C.c_int32),
+        ("neighbor_ranks", c_i32p),
+        ("send_ptr", c_i32p),
+        ("send_idx", c_i32p),
+        ("recv_ptr", c_i32p),
+        ("recv_idx", c_i32p),
     ]
 
 
@@ -219,6 +234,7 @@ SIGNATURES = {
     "tdgl_poisson_set_substructure": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
     "tdgl_poisson_build_substructure": (C.c_int, [_CTX, C.POINTER(SubstructurePlan), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
+    "tdgl_set_deep_halo_plan": (C.c_int, [_CTX, C.POINTER(DeepHaloPlan)]),
     "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),
     "tdgl_comm_init_callbacks": (C.c_int, [_CTX, HALO_FN, ALLREDUCE_FN, C.c_void_p]),

@@ -197,6 +197,7 @@ class Level:
     P: Optional[sp.csr_matrix] = None  # n_l x n_{l+1}
     R: Optional[sp.csr_matrix] = None  # n_{l+1} x n_l  (= P^T, stored CSR)
     agg: Optional[np.ndarray] = None
+    owner: Optional[np.ndarray] = None  # rank that owns each row (build_hierarchy(part=...): the distributed levels)
 
 
 @dataclass
@@ -219,9 +220,16 @@ def build_hierarchy(
     max_levels: int = 12,
     theta: float = 0.0,
     omega: float = 4.0 / 3.0,
+    part: Optional[np.ndarray] = None,
+    part_levels: int = 1,
 ) -> Hierarchy:
     """Build the SA-AMG hierarchy for a symmetric positive semi-definite ``A`` whose null
-    space is the constant vector."""
+    space is the constant vector.
+
+    ``part`` (one-process-per-GPU runs): the rank that owns every fine site.  On the first ``part_levels``
+    levels the aggregation then ignores couplings between sites of different ranks, so every aggregate -- every
+    row of the next level -- lies inside one rank and has one owner (`Level.owner`); the prolongator smoothing
+    still uses the whole matrix, so the hierarchy remains a plain smoothed-aggregation one of the GLOBAL operator."""
     A = sp.csr_matrix(A, dtype=float)
     A.sum_duplicates()
     A.sort_indices()
@@ -232,6 +240,8 @@ def build_hierarchy(
         dinv = np.where(diag > 0, 1.0 / np.where(diag > 0, diag, 1.0), 0.0)
         rho = 1.05 * estimate_rho_DinvA(A, dinv, seed=lvl)
         level = Level(A=A, dinv=dinv, rho=rho)
+        if part is not None:
+            level.owner = np.asarray(part, dtype=np.int32)
         h.levels.append(level)
         if n <= max_coarse or lvl == max_levels - 1:
             break
@@ -240,12 +250,22 @@ def build_hierarchy(
         off = C.row != C.col
         keep = off & (np.abs(C.data) >= theta * np.sqrt(np.abs(diag[C.row] * diag[C.col])))
         keep &= C.data != 0
+        if part is not None and lvl < part_levels:
+            keep &= part[C.row] == part[C.col]
         S = sp.csr_matrix((C.data[keep], (C.row[keep], C.col[keep])), shape=A.shape)
         S.sort_indices()
         agg, n_agg = mis2_aggregate(S, seed=lvl)
         if n_agg >= n:  # no coarsening possible
             break
         T = sp.csr_matrix((np.ones(n), (np.arange(n), agg)), shape=(n, n_agg))
+        if part is not None:
+            if lvl < part_levels:  # every member of an aggregate has the same owner
+                nxt = np.zeros(n_agg, dtype=np.int32)
+                nxt[agg] = part
+                assert (nxt[agg] == part).all()
+                part = nxt
+            else:
+                part = None
         DinvA = sp.diags(dinv) @ A
         P = (T - (omega / rho) * _mm(DinvA, T)).tocsr()
         P.sort_indices()

@@ -28,7 +28,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL 
 
 from .amg import build_hierarchy
 from .hipcore import TDGLContext, poisson_matrix
-from .partition import build_local_problem, local_hierarchy_level0, rcb_partition
+from .partition import (DeepPlanner, build_local_problem, deep_plan_applicable, link_deep_plans, local_hierarchy_level0,
+                        rcb_partition)
 
 
 @contextlib.contextmanager
@@ -75,12 +76,18 @@ def prepare_payloads(mesh, world, link_exponents, epsilon=1.0, **kw):
 
 
 def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, terminal_info=(), mu_boundary=None,
-                         probe_points=None, screening=None, max_coarse=None, hierarchy=None):
+                         probe_points=None, screening=None, max_coarse=None, hierarchy=None, deep="auto", plan_kw=None):
     """Everything the ranks of a `world`-way run need, computed ONCE (by the root rank or ahead of
     time): the partition, each rank's sub-mesh + halo plan, its slice of AMG level 0 and of the
     inputs, and the coarse levels (replicated, one shared object).  Returns a list of `world`
     dicts; `DistributedTDGL(payload=...)` consumes one.  The counterpart of the reference's
-    single `MeshOperators.build_operators()` (operators.py:282-308) for a decomposed mesh."""
+    single `MeshOperators.build_operators()` (operators.py:282-308) for a decomposed mesh.
+
+    ``deep``: ``"auto"`` (default) distributes TWO levels of the hierarchy with one vector exchange per PCG iteration
+    (`partition.DeepPlanner`) whenever level 1 is an intermediate level of the collapsed chain (meshes from ~30k
+    sites on); ``False`` keeps everything below level 0 replicated (small meshes fall back to that by themselves);
+    ``True`` insists.  ``plan_kw``: arguments of `amg.collapsed_operators` (tests: ``tail_rows`` / ``dense_rows`` small
+    enough to make level 1 an intermediate level of a small hierarchy)."""
     em = mesh.edge_mesh
     n, m = len(mesh.sites), len(em.edges)
     fixed = (
@@ -91,8 +98,10 @@ def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, ter
     part = rcb_partition(mesh.sites, int(world))
     if hierarchy is None:
         A_glob = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
-        # (level 0 is the distributed one, so the hierarchy needs at least one coarser level)
-        hierarchy = build_hierarchy(A_glob, max_coarse=max_coarse or min(600, max(8, n // 4)))
+        # (level 0 is the distributed one, so the hierarchy needs at least one coarser level; the aggregates of
+        # level 0 stay inside ranks, so that level 1 can be distributed as well)
+        hierarchy = build_hierarchy(A_glob, max_coarse=max_coarse or min(600, max(8, n // 4)),
+                                    part=part if deep else None)
     coarse = dict(levels=list(hierarchy.levels[1:]), coarse_pinv=hierarchy.coarse_pinv,
                   sizes=hierarchy.sizes, operator_complexity=hierarchy.operator_complexity)
     # the collapsed coarse chain involves only the replicated levels: built once here for the default
@@ -101,17 +110,32 @@ def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, ter
     from .amg import collapsed_operators
 
     coarse["plan_key"] = (2, 1, 0.1, True, 2)  # nu, smoother (chebyshev), cheb_lo, collapse, tail_cycles
-    coarse["plan"] = collapsed_operators(hierarchy, 2, "chebyshev", 0.1, tail_cycles=2)
+    coarse["plan"] = collapsed_operators(hierarchy, 2, "chebyshev", 0.1, tail_cycles=2, **(plan_kw or {}))
+    use_deep = bool(deep) and deep_plan_applicable(hierarchy, coarse["plan"])
+    if deep is True and not use_deep:
+        raise ValueError("deep=True: level 1 of this hierarchy is not an intermediate level of the collapsed chain "
+                         f"(sizes {hierarchy.sizes})")
+    planner = None
+    if use_deep:
+        planner = DeepPlanner(hierarchy, coarse["plan"], part)
+        # levels >= 2 are the replicated ones now; level 1 travels as per-rank slices
+        coarse = dict(coarse, levels=list(hierarchy.levels[2:]), rho1=float(hierarchy.levels[1].rho))
     A_e = np.asarray(link_exponents, dtype=float)
     eps = np.asarray(epsilon, dtype=float) * np.ones(n)
     mu_b = np.zeros(len(em.boundary_edge_indices)) if mu_boundary is None else np.asarray(mu_boundary, dtype=float)
     probes = None if probe_points is None else np.asarray(probe_points, dtype=np.int64)
     out = []
+    deep_plans = {}
+    if use_deep:  # send lists come from the OTHER ranks' receive lists: all pieces are cut together
+        all_lps = {r: build_local_problem(mesh, part, r, fixed_sites=fixed) for r in range(int(world))}
+        deep_plans = {r: planner.cut(all_lps[r]) for r in range(int(world))}
+        link_deep_plans(deep_plans, all_lps)
     for r in ranks:
-        lp = build_local_problem(mesh, part, r, fixed_sites=fixed)
+        lp = all_lps[r] if use_deep else build_local_problem(mesh, part, r, fixed_sites=fixed)
         l2g = lp.local_to_global
         pay = dict(
-            rank=r, world=int(world), n_global=n, m_global=m, lp=lp, level0=local_hierarchy_level0(hierarchy, lp),
+            rank=r, world=int(world), n_global=n, m_global=m, lp=lp,
+            level0=None if use_deep else local_hierarchy_level0(hierarchy, lp), deep=deep_plans.get(r),
             coarse=coarse, link_exponents=A_e[lp.edge_local_to_global], epsilon=eps[l2g],
             mu_boundary=mu_b[lp.boundary_positions], n_probes=0 if probes is None else len(probes),
         )
@@ -129,12 +153,12 @@ def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, ter
 
 
 def _own_payload(mesh, world, rank, link_exponents, epsilon, terminal_info, mu_boundary, probe_points, screening,
-                 max_coarse):
+                 max_coarse, deep="auto", plan_kw=None):
     """Legacy construction: every rank holds the global mesh and prepares only its own piece (the
     global hierarchy is still built on every rank -- fine for small problems and tests)."""
     pieces = prepare_payloads_for(mesh, world, [rank], link_exponents, epsilon, terminal_info=terminal_info,
                                   mu_boundary=mu_boundary, probe_points=probe_points, screening=screening,
-                                  max_coarse=max_coarse)
+                                  max_coarse=max_coarse, deep=deep, plan_kw=plan_kw)
     return pieces[0]
 
 
@@ -152,7 +176,7 @@ class DistributedTDGL:
 
     def __init__(self, mesh, options, link_exponents=None, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
                  terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
-                 overlap="auto", screening=None, root=None, payload=None, max_coarse=None):
+                 overlap="auto", screening=None, root=None, payload=None, max_coarse=None, deep="auto", plan_kw=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -165,13 +189,13 @@ class DistributedTDGL:
         if payload is None:
             if root is None:
                 payload = _own_payload(mesh, self.world, self.rank, link_exponents, epsilon, terminal_info,
-                                       mu_boundary, probe_points, screening, max_coarse)
+                                       mu_boundary, probe_points, screening, max_coarse, deep, plan_kw)
             else:
                 pieces = None
                 if self.rank == int(root):
                     pieces = prepare_payloads(mesh, self.world, link_exponents, epsilon, terminal_info=terminal_info,
                                               mu_boundary=mu_boundary, probe_points=probe_points,
-                                              screening=screening, max_coarse=max_coarse)
+                                              screening=screening, max_coarse=max_coarse, deep=deep, plan_kw=plan_kw)
                 if self.world > 1:
                     got = [None]
                     dist.scatter_object_list(got, pieces, src=int(root))
@@ -187,6 +211,9 @@ class DistributedTDGL:
             device_id=dev, n_owned=lp.n_own,
         )
         ctx.set_halo_plan(lp)
+        self.deep = payload.get("deep")
+        if self.deep is not None:
+            ctx.set_deep_halo_plan(self.deep)
         ctx.set_comm_overlap(overlap)  # halo exchanges hidden behind the ghost-free rows
         if self.world > 1 or transport == "rccl":
             if transport == "rccl":
@@ -198,7 +225,12 @@ class DistributedTDGL:
                 ctx.comm_init_callbacks(self._halo_cb, self._allreduce_cb)
             else:
                 raise ValueError(f"unknown transport {transport!r}")
-        ctx.set_hierarchy_sliced(payload["level0"], payload["coarse"], lp)
+        if self.deep is not None:
+            ctx.set_poisson_options(rtol=options.pcg_rtol, max_iter=options.pcg_max_iter, nu=options.amg_smoothing_sweeps,
+                                    edge_currents_every_step=options.edge_currents_every_step)
+            ctx.set_hierarchy_deep(self.deep, payload["coarse"])
+        else:
+            ctx.set_hierarchy_sliced(payload["level0"], payload["coarse"], lp)
         self.hierarchy = ctx.hierarchy
         ctx.set_poisson_options(
             rtol=options.pcg_rtol, max_iter=options.pcg_max_iter, nu=options.amg_smoothing_sweeps,
@@ -230,12 +262,15 @@ class DistributedTDGL:
 
         dist = self.dist
         reqs, bufs = [], []
+        # (an empty list on this side is an empty list on the other side: both skip the message)
         for k, nb in enumerate(ranks):
             t = torch.empty(int(recv_off[k + 1] - recv_off[k]), dtype=torch.float64)
             bufs.append(t)
-            reqs.append(dist.irecv(t, src=int(nb)))
+            if t.numel():
+                reqs.append(dist.irecv(t, src=int(nb)))
         for k, nb in enumerate(ranks):
-            reqs.append(dist.isend(torch.from_numpy(send[send_off[k]:send_off[k + 1]].copy()), dst=int(nb)))
+            if send_off[k + 1] > send_off[k]:
+                reqs.append(dist.isend(torch.from_numpy(send[send_off[k]:send_off[k + 1]].copy()), dst=int(nb)))
         for r in reqs:
             r.wait()
         for k in range(len(ranks)):

@@ -323,6 +323,24 @@ class TDGLContext:
         )
         self._chk(self._lib.tdgl_set_halo_plan(self._ctx, C.byref(plan)))
 
+    def set_deep_halo_plan(self, dp):
+        """Register the exchange of the PCG residual on the whole ghost zone of `partition.DeepPlan` ``dp``
+        (`tdgl_set_deep_halo_plan`; after `set_halo_plan`, before `set_hierarchy_deep`)."""
+        nbrs = sorted(set(dp.neighbors) | set(dp.send_idx))
+        empty = np.empty(0, dtype=np.int64)
+        send = [np.asarray(dp.send_idx.get(nb, empty)) for nb in nbrs]
+        recv = [np.asarray(dp.recv_idx.get(nb, empty)) for nb in nbrs]
+        a = (i32(nbrs), i32(np.concatenate([[0], np.cumsum([len(x) for x in send])])),
+             i32(np.concatenate(send) if send else []), i32(np.concatenate([[0], np.cumsum([len(x) for x in recv])])),
+             i32(np.concatenate(recv) if recv else []))
+        self._deep_keep = a
+        plan = _lib.DeepHaloPlan(
+            n_ext=int(dp.n_ext), n_neighbors=len(nbrs), neighbor_ranks=p_i32(a[0]) if len(nbrs) else None,
+            send_ptr=p_i32(a[1]), send_idx=p_i32(a[2]) if len(a[2]) else None, recv_ptr=p_i32(a[3]),
+            recv_idx=p_i32(a[4]) if len(a[4]) else None)
+        self._chk(self._lib.tdgl_set_deep_halo_plan(self._ctx, C.byref(plan)))
+        self.deep_plan = dp
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = C.create_string_buffer(128)
@@ -409,6 +427,62 @@ class TDGLContext:
         self.set_hierarchy(hh, n_cols0=lp.n_loc)
         self.hierarchy = _HierarchyInfo(hh, coarse.get("sizes"), coarse.get("operator_complexity"))
 
+    def set_hierarchy_deep(self, dp, coarse: dict):
+        """Two distributed AMG levels (`partition.DeepPlan` ``dp``: this rank's slices of level 0 and of the explicit
+        operators of level 1) on top of the replicated levels >= 2 (``coarse``: ``levels`` = the global hierarchy's
+        levels from 2 on, ``coarse_pinv``, ``plan`` = its collapsed chain)."""
+        from .amg import Level
+
+        lv0 = Level(A=dp.A, dinv=dp.dinv, rho=dp.rho, P=dp.P, R=None)
+        stub = Level(A=None, dinv=None, rho=float(coarse["rho1"]))
+        hh = Hierarchy(levels=[lv0, stub] + list(coarse["levels"]), coarse_pinv=coarse["coarse_pinv"])
+        levels = (_lib.AmgLevel * len(hh.levels))()
+        keep = []
+        for idx, lv in enumerate(hh.levels):
+            L = levels[idx]
+            L.rho = float(lv.rho)
+            if idx == 1:
+                L.n, L.n_cols, L.explicit_only, L.n_coarse = int(dp.l1_x), int(dp.l1_loc), 1, int(dp.M.shape[0])
+                continue
+            A = lv.A.tocsr()
+            arrs = dict(Ap=i32(A.indptr), Ai=i32(A.indices), Ad=f64(A.data), dinv=f64(lv.dinv))
+            L.A_indptr, L.A_indices, L.A_data, L.dinv = p_i32(arrs["Ap"]), p_i32(arrs["Ai"]), p_f64(arrs["Ad"]), p_f64(arrs["dinv"])
+            if idx == 0:
+                L.n, L.n_cols, L.a_rows, L.p_rows = int(dp.n_own), int(dp.n_ext), int(dp.n1), int(dp.n2)
+                P = lv.P.tocsr()
+                arrs.update(Pp=i32(P.indptr), Pi=i32(P.indices), Pd=f64(P.data))
+                L.n_coarse = int(dp.l1_x)
+                L.P_indptr, L.P_indices, L.P_data = p_i32(arrs["Pp"]), p_i32(arrs["Pi"]), p_f64(arrs["Pd"])
+            else:
+                L.n = A.shape[0]
+                if lv.P is not None:
+                    P, R = lv.P.tocsr(), lv.R.tocsr()
+                    arrs.update(Pp=i32(P.indptr), Pi=i32(P.indices), Pd=f64(P.data),
+                                Rp=i32(R.indptr), Ri=i32(R.indices), Rd=f64(R.data))
+                    L.n_coarse = P.shape[1]
+                    L.P_indptr, L.P_indices, L.P_data = p_i32(arrs["Pp"]), p_i32(arrs["Pi"]), p_f64(arrs["Pd"])
+                    L.R_indptr, L.R_indices, L.R_data = p_i32(arrs["Rp"]), p_i32(arrs["Ri"]), p_f64(arrs["Rd"])
+            keep.append(arrs)
+        pinv = f64(hh.coarse_pinv)
+        with _Stopwatch(self.setup_times, "upload"):
+            self._chk(self._lib.tdgl_poisson_set_hierarchy(self._ctx, levels, len(hh.levels), p_f64(pinv)))
+        self._local_level0 = None
+        self._deep = dp
+        # the plan of the collapsed chain with this rank's slices in the place of level 1
+        plan = dict(coarse["plan"])
+        plan["mid"] = dict(plan["mid"]); plan["up"] = dict(plan["up"])
+        plan["mid"][1] = dp.M
+        plan["up"][1] = (dp.W, dp.V)
+        self._shipped_plan = (coarse.get("plan_key"), plan)
+        self.hierarchy = _HierarchyInfo(hh, coarse.get("sizes"), coarse.get("operator_complexity"))
+        self.hierarchy.levels = hh.levels
+        self.dense_direct = False
+        self.substructure = None
+        self._hier_epoch = getattr(self, "_hier_epoch", 0) + 1
+        self._refresh_fused_restriction()
+        self._set_fused_levels(hh)
+        self._refresh_collapsed()
+
     def set_hierarchy(self, h: Hierarchy, n_cols0: int = 0):
         levels = (_lib.AmgLevel * len(h.levels))()
         keep = []
@@ -450,6 +524,8 @@ class TDGLContext:
         from .amg import fused_level_operators
 
         for k in range(1, len(h.levels) - 1):
+            if h.levels[k].A is None:  # a distributed level 1 (set_hierarchy_deep): explicit operators only
+                continue
             if not on:
                 self._chk(self._lib.tdgl_poisson_set_fused_level(self._ctx, k, None, None, None, None, None, None, None))
                 continue
@@ -476,6 +552,21 @@ class TDGLContext:
         name = "jacobi" if o["smoother"] == 0 else "chebyshev"
         c = smoother_coefficients(h.levels[0].rho, 1, name, o["cheb_lo"])[1][0]
         lv0 = getattr(self, "_local_level0", None)
+        dp = getattr(self, "_deep", None)
+        if dp is not None:  # two distributed levels: the rows the root cut for this rank, for ITS coefficient
+            if abs(dp.c - c) > 1e-12 * c:
+                raise ValueError("the two-level decomposition was prepared for the default smoother settings "
+                                 f"(level-0 coefficient {dp.c}); these options give {c}")
+            key = (getattr(self, "_hier_epoch", 0), float(c))
+            if getattr(self, "_fusedR_key", None) == key:
+                return
+            M = dp.F
+            ip, ix, dx = i32(M.indptr), i32(M.indices), f64(M.data)
+            with _Stopwatch(self.setup_times, "upload"):
+                self._chk(self._lib.tdgl_poisson_set_fused_restriction(
+                    self._ctx, M.shape[0], M.shape[1], p_i32(ip), p_i32(ix), p_f64(dx), float(c)))
+            self._fusedR_key = key
+            return
         if lv0 is None and self.n_owned != self.n:
             return
         key = (getattr(self, "_hier_epoch", 0), float(c))
@@ -511,6 +602,9 @@ class TDGLContext:
         if shipped is not None and shipped[0] == (o["nu"], o["smoother"], o["cheb_lo"], o.get("collapse", True),
                                                    o.get("tail_cycles", 2)):
             plan = shipped[1]  # built once by the root rank (distributed.prepare_payloads)
+        elif getattr(self, "_deep", None) is not None:
+            raise ValueError("the two-level decomposition was prepared for the default smoother settings; "
+                             f"these options ({o['nu']}, {o['smoother']}, {o['cheb_lo']}) need another set-up")
         else:
             with _Stopwatch(self.setup_times, "amg_host"):
                 plan = collapsed_operators(h, o["nu"], name, o["cheb_lo"], tail_cycles=o.get("tail_cycles", 2)) \

@@ -119,3 +119,92 @@ def gather_global(lp, local_owned_values, n_global, dtype=np.float64):
     t = torch.from_numpy(flat)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.numpy().view(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Two distributed AMG levels, one vector exchange per iteration (tdgl_amd.partition.DeepPlan; csrc/poisson.inc with
+# tdgl_set_deep_halo_plan): the same sequence in NumPy.
+def halo_exchange_deep(dp, vec):
+    """Refresh ALL ghost entries ``vec[n_own:n_ext]`` (the residual's deep ghost zone) in place."""
+    nbrs = sorted(set(dp.neighbors) | set(dp.send_idx))
+    reqs, bufs = [], {}
+    for nb in nbrs:
+        k = len(dp.recv_idx.get(nb, ()))
+        if k:
+            bufs[nb] = torch.empty(k, dtype=torch.float64)
+            reqs.append(dist.irecv(bufs[nb], src=nb))
+    for nb in nbrs:
+        idx = dp.send_idx.get(nb, ())
+        if len(idx):
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(vec[idx])), dst=nb))
+    for r in reqs:
+        r.wait()
+    for nb, t in bufs.items():
+        vec[dp.recv_idx[nb]] = t.numpy()
+
+
+def level2_cycle(h, plan, b2):
+    """The replicated part of the collapsed chain: everything from level 2 down (host model)."""
+    def level(k, bk):
+        if k == plan["tail"]:
+            if plan["mode"] == "dense":
+                return plan["B"] @ bk
+            y = plan["G"] @ bk
+            return plan["W"] @ np.concatenate([bk, y]) + plan["V"] @ y[: plan["V"].shape[1]]
+        W, V = plan["up"][k]
+        return W @ bk + V @ level(k + 1, plan["mid"][k] @ bk)
+
+    return level(2, b2)
+
+
+def vcycle_deep(dp, h, plan, r_ext, counts=None):
+    """z = M^-1 r on the owned rows AND the first ghost layer from r on the whole ghost zone (already exchanged):
+    no further vector exchange, one sum over ranks (the partial level-2 right-hand sides)."""
+    b1 = dp.F @ r_ext
+    b2 = allreduce_sum(dp.M @ b1[: dp.l1_own])
+    if counts is not None:
+        counts["allreduce_values"] += len(b2)
+    x1 = dp.W @ b1 + dp.V @ level2_cycle(h, plan, b2)
+    x = dp.c * dp.dinv[: dp.n2] * r_ext[: dp.n2] + dp.P @ x1
+    return x[: dp.n1] + dp.c * dp.dinv[: dp.n1] * (r_ext[: dp.n1] - dp.A @ x)
+
+
+def pcg_deep(dp, lp, h, plan, b_own, x0_loc=None, rtol=1e-10, maxiter=200):
+    """The single-reduction (Chronopoulos-Gear) PCG the library runs in this mode.  Returns (mu_local with valid
+    first-layer ghosts, iterations, counts of what was communicated)."""
+    n_own, n_glob = dp.n_own, lp.n_global
+    A_own = dp.A[:n_own]
+    counts = dict(deep_exchanges=0, thin_exchanges=0, allreduce_values=0)
+    b = b_own - allreduce_sum(b_own.sum()) / n_glob
+    x = np.zeros(dp.n1) if x0_loc is None else x0_loc.copy()
+    xe = np.zeros(dp.n2)
+    xe[: dp.n1] = x
+    r = np.zeros(dp.n_ext)
+    r[:n_own] = b - A_own @ xe
+    bb = allreduce_sum(b @ b)
+    rr = allreduce_sum(r[:n_own] @ r[:n_own])
+    p, q = np.zeros(n_own), np.zeros(n_own)
+    rz_old = alpha_old = None
+    it = 0
+    while rr > rtol * rtol * bb and it < maxiter:
+        halo_exchange_deep(dp, r)
+        counts["deep_exchanges"] += 1
+        z = vcycle_deep(dp, h, plan, r, counts)            # valid on [0, n1)
+        ze = np.zeros(dp.n2)
+        ze[: dp.n1] = z
+        w = A_own @ ze                                      # no exchange: z's first ghost layer was formed locally
+        rz, zw = allreduce_sum(np.array([r[:n_own] @ z[:n_own], z[:n_own] @ w]))
+        counts["allreduce_values"] += 2
+        beta = 0.0 if rz_old is None else rz / rz_old
+        alpha = rz / (zw - (0.0 if rz_old is None else beta * rz / alpha_old))
+        p = z[:n_own] + beta * p
+        q = w + beta * q
+        x[:n_own] += alpha * p
+        r[:n_own] -= alpha * q
+        rr = allreduce_sum(r[:n_own] @ r[:n_own])
+        rz_old, alpha_old = rz, alpha
+        it += 1
+    x[:n_own] -= allreduce_sum(x[:n_own].sum()) / n_glob
+    halo_exchange(lp, x)
+    counts["thin_exchanges"] += 1
+    return x, it, counts

@@ -5,6 +5,8 @@ import os
 import socket
 import sys
 
+from types import SimpleNamespace
+
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
@@ -224,6 +226,89 @@ def test_distributed_step_matches_single_domain_oracle(world, case, tmp_path):
     assert res["psi_err"] < 1e-14  # pointwise update of identical inputs
     assert res["js_err"] < 1e-13
     assert res["mu_err"] < 1e-9  # PCG to 1e-12 vs LU, modulo the constant
+
+
+# ---------------------------------------------------------------- two distributed levels
+def _deep_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_model import gather_global, pcg_deep
+        from tdgl_amd.distributed import prepare_payloads_for
+
+        mesh = synthetic_mesh(150, 110)  # 19k sites: hierarchy [19k, 1.9k, 190, ...]
+        n = len(mesh.sites)
+        # every rank cuts its own piece from the global mesh (tests): level 1 is made an intermediate level
+        pay = prepare_payloads_for(mesh, world, [rank], uniform_field_A(mesh, 0.05), 1.0, deep=True, max_coarse=50,
+                                   plan_kw=dict(tail_rows=1200, dense_rows=400))[0]
+        dp, lp, coarse = pay["deep"], pay["lp"], pay["coarse"]
+        hh = SimpleNamespace(levels=[None, None] + list(coarse["levels"]))
+        rng = np.random.default_rng(11)
+        b = rng.standard_normal(n)
+        b -= b.mean()
+        x, iters, counts = pcg_deep(dp, lp, hh, coarse["plan"], b[lp.local_to_global[: lp.n_own]], rtol=1e-11)
+        mu = gather_global(lp, x[: lp.n_own], n)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"deep_{world}.npz"), mu=mu, iters=iters, b=b,
+                     deep_exchanges=counts["deep_exchanges"], thin_exchanges=counts["thin_exchanges"],
+                     allreduce_values=counts["allreduce_values"], n_level2=coarse["levels"][0].A.shape[0],
+                     ghosts=dp.n_ext - dp.n_own, layer1=dp.n1 - dp.n_own, n_own=dp.n_own, l1=(dp.l1_own, dp.l1_x, dp.l1_loc))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_distributed_levels_one_exchange_per_iteration(world, tmp_path):
+    """The decomposition with TWO distributed AMG levels (partition.DeepPlanner): per-rank
+    aggregates, level 1 through its explicit operators, everything a rank would have to receive inside an iteration
+    formed redundantly from ONE exchange of the residual on a deep ghost zone.  The NumPy model of the library's
+    sequence under gloo against the single-domain PCG with the same hierarchy: the same solution, the same iteration
+    count, and per iteration exactly one vector exchange and one level-2-sized sum."""
+    import scipy.sparse.linalg as spla
+
+    from tdgl_amd.amg import build_hierarchy, collapsed_operators, vcycle_collapsed_host
+    from tdgl_amd.hipcore import poisson_matrix
+    from tdgl_amd.partition import rcb_partition
+
+    mp.spawn(_deep_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"deep_{world}.npz"))
+    mesh = synthetic_mesh(150, 110)
+    em, n = mesh.edge_mesh, len(mesh.sites)
+    A = poisson_matrix(em.edges, em.dual_edge_lengths / em.edge_lengths, n)
+    part = rcb_partition(mesh.sites, world)
+    h = build_hierarchy(A, max_coarse=50, part=part)
+    plan = collapsed_operators(h, 2, "chebyshev", 0.1, tail_cycles=2, tail_rows=1200, dense_rows=400)
+    assert plan["tail"] == 2 and int(got["n_level2"]) == h.sizes[2]
+    # single-domain PCG with the collapsed cycle of the same hierarchy
+    b = got["b"]
+    x, r = np.zeros(n), b.copy()
+    z = vcycle_collapsed_host(h, plan, r, nu_fine=1)
+    p, rz, it = z.copy(), r @ z, 0
+    while np.linalg.norm(r) > 1e-11 * np.linalg.norm(b):
+        q = A @ p
+        a = rz / (p @ q)
+        x += a * p
+        r -= a * q
+        it += 1
+        z = vcycle_collapsed_host(h, plan, r, nu_fine=1)
+        rz, rz_old = r @ z, rz
+        p = z + (rz / rz_old) * p
+    x -= x.mean()
+    assert abs(int(got["iters"]) - it) <= 1
+    assert np.abs(got["mu"] - x).max() < 1e-8 * np.abs(x).max()
+    assert np.linalg.norm(A @ got["mu"] - b) < 1e-10 * np.linalg.norm(b)
+    its = int(got["iters"])
+    assert int(got["deep_exchanges"]) == its and int(got["thin_exchanges"]) == 1
+    assert int(got["allreduce_values"]) == its * (h.sizes[2] + 2)
+    # the deep ghost zone is a multiple of the first layer, the redundant level-1 work a fraction of the owned part
+    assert int(got["layer1"]) < int(got["ghosts"]) < 40 * int(got["layer1"])
+    l1_own, l1_x, l1_loc = got["l1"]
+    assert l1_own <= l1_x <= l1_loc < 2 * l1_own
 
 
 # ---------------------------------------------------------------- root-built pieces
