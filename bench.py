@@ -320,6 +320,9 @@ def main():
                     help="decomposed runs: rccl = one GPU per rank, exchanges inside tdgl_run over RCCL (the product path); "
                          "gloo = host callbacks + torch.distributed, all ranks may share ONE GPU (a dry run of the decomposition: "
                          "message counts and sizes are real, timings are not)")
+    ap.add_argument("--dist-levels", type=int, choices=[1, 2], default=2,
+                    help="decomposed runs: 2 (default) = levels 0 and 1 of the AMG hierarchy distributed, one vector exchange "
+                         "per PCG iteration (partition.DeepPlanner); 1 = level 0 only, everything below replicated (rounds 1-4)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the domain-decomposition driver (RCCL communicator) even on one GPU")
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
@@ -394,7 +397,8 @@ def main():
             from tdgl_amd.distributed import DistributedTDGL
 
             drun = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
-                                   rank=rank, world=world, transport=args.transport, device_id=local_rank, root=0)
+                                   rank=rank, world=world, transport=args.transport, device_id=local_rank, root=0,
+                                   deep="auto" if args.dist_levels == 2 else False)
             ctx = drun.ctx
             n_loc, m_loc, n, m = drun.lp.n_own, len(drun.lp.edge_local_to_global), drun.n_global, drun.m_global
             drun.set_state(1.0, 0.0)
@@ -658,6 +662,17 @@ def main():
                 neighbours=len(r.drun.lp.neighbors), ghost_sites=int(r.drun.lp.n_ghost),
                 overlap=bool(r.overlap[0]), interior_rows=int(r.overlap[1]),
             )
+            dp = getattr(r.drun, "deep", None)
+            d["comm_per_step"]["decomposition"] = (
+                "level 0 distributed, levels >= 1 replicated (three first-layer exchanges and a level-1-sized sum per iteration)"
+                if dp is None else
+                "levels 0 and 1 distributed (per-rank aggregates), levels >= 2 replicated: per iteration ONE exchange of the "
+                "residual on a deep ghost zone, a level-2-sized sum, the CG's dot products")
+            if dp is not None:
+                d["comm_per_step"].update(
+                    deep_ghost_entries=int(dp.n_ext - dp.n_own), deep_neighbours=len(set(dp.neighbors) | set(dp.send_idx)),
+                    level1_rows=dict(owned=int(dp.l1_own), x_formed=int(dp.l1_x), b_formed=int(dp.l1_loc)),
+                    summed_per_iteration=dict(level2_values_fp32=int(dp.M.shape[0]), dot_partials_fp64=3 * 1024))
         return d
 
     main_line = line_for(main_run) if rank == 0 else None

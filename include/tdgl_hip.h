@@ -384,6 +384,19 @@ typedef int (*tdgl_halo_fn)(void *user, const double *send, const int64_t *send_
                             const int64_t *recv_off, int32_t n_neighbors, const int32_t *neighbor_ranks);
 typedef int (*tdgl_allreduce_fn)(void *user, double *buf, int64_t count, int32_t op);
 int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn allreduce, void *user);
+/* Peer-mapped transport (the ranks of ONE node; csrc/ipc.inc): every rank owns an inbox in device memory, exported
+ * with hipIpcGetMemHandle and opened by the others -- on the same GPU or on a peer over xGMI.  A halo exchange is one
+ * launch that stores the owned values straight into the neighbours' inboxes and raises a flag there, and one launch
+ * that waits for the neighbours' flags and scatters the inbox into the ghost entries; an all-reduce is one launch that
+ * stores the vector into slot [rank] of every inbox and one that adds the slots in rank order (the same bits on every
+ * rank).  Everything runs on the context's one stream: no host synchronisation, no second stream, and work that reads
+ * no ghost values is queued between the two launches of an exchange (the overlap is then always on).  Waits are bounded
+ * (8 s): a rank that died turns into TDGL_ERR_HIP at the end of tdgl_run, not into a hang.
+ * Set-up (after tdgl_set_halo_plan / tdgl_set_deep_halo_plan): every rank calls tdgl_comm_ipc_export (handle64: the
+ * 64-byte IPC handle of its inbox; table[4 + 6 world]: where in that inbox each rank's values land), the host layer
+ * all-gathers both, every rank calls tdgl_comm_init_ipc with the `world` handles and tables in rank order. */
+int tdgl_comm_ipc_export(tdgl_ctx *ctx, char *handle64, int64_t *table, int64_t table_len);
+int tdgl_comm_init_ipc(tdgl_ctx *ctx, const char *handles, const int64_t *tables);
 /* Overlap of the halo exchanges with the ghost-free rows: the stencil kernels that follow an
  * exchange (psi Laplacian + rhs; level-0 residual of the V-cycle; A p of the CG; edge currents)
  * run their leading ghost-free part on the compute stream while the exchange travels on a second
@@ -394,6 +407,14 @@ int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn
  * tdgl_get_comm_overlap reports whether exchanges are overlapped with the current plan. */
 int tdgl_set_comm_overlap(tdgl_ctx *ctx, int32_t on);
 int tdgl_get_comm_overlap(tdgl_ctx *ctx, int32_t *enabled, int64_t *interior_rows);
+/* Transport self-test: ONE exchange of the ghost entries of a caller-supplied vector (vec_inout: n_sites * width
+ * doubles, or n_ext with deep = 1 -- the owned entries go out, the ghost entries come back filled) / ONE in-place sum or
+ * maximum of `count` doubles over the ranks (as_f32: carried as floats, like the level-2 right-hand side), through
+ * whatever transport the context was given.  Every rank must call them in the same order.  The host layer
+ * (DistributedTDGL.selftest, bench.py --selftest) fills the vectors with functions of the GLOBAL site id and checks what
+ * arrives: the first contact of N real ranks then yields "rank 3, neighbour 5, entry 17" instead of a hang. */
+int tdgl_comm_test_halo(tdgl_ctx *ctx, double *vec_inout, int32_t width, int32_t deep);
+int tdgl_comm_test_allreduce(tdgl_ctx *ctx, double *buf_inout, int64_t count, int32_t op, int32_t as_f32);
 /* Communication counters of this rank since creation / the last reset:
  * out4 = {halo exchanges, bytes sent in them, all-reduces, bytes all-reduced}. */
 int tdgl_get_comm_stats(tdgl_ctx *ctx, int64_t *out4, int32_t reset);

@@ -150,12 +150,15 @@ extern "C" const char *tdgl_last_error(const tdgl_ctx *ctx) {
     return ctx ? ctx->err.c_str() : g_last_error.c_str();
 }
 
+static void ipc_free(tdgl_ctx *ctx);  // ipc.inc
+
 extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto *lv : ctx->levels) delete lv;
     if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+    ipc_free(ctx);
     if (ctx->h_sendbuf) (void)hipHostFree(ctx->h_sendbuf);
     if (ctx->h_recvbuf) (void)hipHostFree(ctx->h_recvbuf);
     if (ctx->h_deep_send) (void)hipHostFree(ctx->h_deep_send);
@@ -591,6 +594,7 @@ static inline int64_t now_ns() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+#include "ipc.inc"
 #include "comm.inc"
 #include "poisson.inc"
 #include "dense.inc"

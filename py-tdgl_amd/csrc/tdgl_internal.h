@@ -195,6 +195,8 @@ struct StepStatus {
 
 }  // namespace tdgl
 
+struct IpcState;  // peer-mapped transport (ipc.inc)
+
 struct tdgl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -228,6 +230,7 @@ struct tdgl_ctx {
     int64_t stat_halos = 0, stat_halo_bytes = 0, stat_allreduces = 0, stat_allreduce_bytes = 0;
     double *pend_v = nullptr; // exchange started by comm_halo_start, completed by comm_halo_wait
     int pend_width = 0;
+    IpcState *ipc = nullptr;  // peer-mapped transport (tdgl_comm_init_ipc)
     // two distributed AMG levels (tdgl_set_deep_halo_plan): the exchange of r on the whole ghost zone
     bool deep = false;
     int64_t n_ext = 0;        // owned + every ghost layer (length of the PCG's level-0 vectors)

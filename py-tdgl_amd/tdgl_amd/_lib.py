@@ -237,6 +237,10 @@ SIGNATURES = {
     "tdgl_set_deep_halo_plan": (C.c_int, [_CTX, C.POINTER(DeepHaloPlan)]),
     "tdgl_comm_unique_id": (C.c_int, [C.c_char_p]),
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),
+    "tdgl_comm_ipc_export": (C.c_int, [_CTX, C.c_char_p, c_i64p, C.c_int64]),
+    "tdgl_comm_init_ipc": (C.c_int, [_CTX, C.c_char_p, c_i64p]),
+    "tdgl_comm_test_halo": (C.c_int, [_CTX, c_f64p, C.c_int32, C.c_int32]),
+    "tdgl_comm_test_allreduce": (C.c_int, [_CTX, c_f64p, C.c_int64, C.c_int32, C.c_int32]),
     "tdgl_comm_init_callbacks": (C.c_int, [_CTX, HALO_FN, ALLREDUCE_FN, C.c_void_p]),
     "tdgl_set_comm_overlap": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_get_comm_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.c_int32]),

@@ -12,7 +12,9 @@ Usage (every rank of a `torch.distributed` job runs the same code):
 The mesh is cut by recursive coordinate bisection (`partition.rcb_partition`).  With ``root=0`` only
 rank 0 holds the global mesh: it builds the partition and the AMG hierarchy once and scatters each
 rank's piece (`prepare_payloads`); without it every rank cuts its own piece from the global mesh.  The exchange of ghost values and the
-all-reduces run inside `tdgl_run` over RCCL on the context's stream (transport "rccl"); transport
+all-reduces run inside `tdgl_run` on the context's stream: transport "rccl" (ncclSend/Recv, ncclAllReduce), or
+transport "ipc" -- neighbours' kernels store straight into each other's device memory (hipIpc-mapped inboxes, flags
+polled by the receiving kernel: csrc/ipc.inc; the ranks of one node, also when they share a GPU).  Transport
 "gloo" routes them through host callbacks and torch.distributed instead -- slow, used by the test
 suite so that several ranks can share one GPU.
 """
@@ -221,6 +223,15 @@ class DistributedTDGL:
                 dist.broadcast_object_list(ident, src=0)
                 with stdout_to_stderr():
                     ctx.comm_init_rccl(ident[0])
+            elif transport == "ipc":
+                # peer-mapped inboxes (csrc/ipc.inc): handles and slot tables travel over the bootstrap group
+                mine = ctx.comm_ipc_export(self.world)
+                everyone = [None] * self.world
+                if self.world > 1:
+                    dist.all_gather_object(everyone, mine)
+                else:
+                    everyone = [mine]
+                ctx.comm_init_ipc([e[0] for e in everyone], [e[1] for e in everyone])
             elif transport == "gloo":
                 ctx.comm_init_callbacks(self._halo_cb, self._allreduce_cb)
             else:
@@ -282,6 +293,63 @@ class DistributedTDGL:
         t = torch.from_numpy(buf.copy())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX)
         buf[:] = t.numpy()
+
+    # -- first contact ----------------------------------------------------------------------------
+    def selftest(self):
+        """One exchange per pattern and one sum per kind through the transport in use, on values that are functions
+        of the GLOBAL site id / of the rank, checked entry by entry.  Every rank calls it; returns a report
+        (``dict(ok, rank, device, neighbours, checks=[...])``) instead of raising, so that a launcher can print all
+        ranks' findings.  (`tdgl_comm_test_halo`, `tdgl_comm_test_allreduce`)"""
+        lp, ctx, w = self.lp, self.ctx, self.world
+        report = dict(rank=self.rank, world=w, neighbours=list(lp.neighbors), n_own=int(lp.n_own), ghosts=int(lp.n_ghost), checks=[])
+
+        def f(gid, c=0):  # exactly representable, different for every site and component
+            return (np.asarray(gid, dtype=np.float64) * 4.0 + c + 1.0)
+
+        def check(name, got, want, who):
+            bad = np.flatnonzero(got != want)
+            entry = dict(name=name, ok=len(bad) == 0, entries=int(len(want)))
+            if len(bad):
+                k = int(bad[0])
+                entry.update(first_bad=k, owner=int(who[k]) if who is not None else None, got=float(got[k]), want=float(want[k]),
+                             n_bad=int(len(bad)))
+            report["checks"].append(entry)
+
+        try:
+            l2g = lp.local_to_global
+            part_of_ghost = None
+            for width in (1, 2):  # mu / the PCG vectors; psi
+                v = np.full((len(l2g), width), -1.0)
+                for c in range(width):
+                    v[: lp.n_own, c] = f(l2g[: lp.n_own], c)
+                got = ctx.comm_test_halo(v.ravel(), width=width).reshape(len(l2g), width)
+                want = np.stack([f(l2g, c) for c in range(width)], axis=1)
+                owner = np.concatenate([np.full(b - a, nb) for nb, (a, b) in sorted(lp.recv_range.items(), key=lambda kv: kv[1][0])]) \
+                    if lp.neighbors else np.empty(0, dtype=int)
+                part_of_ghost = np.repeat(owner, width) if len(owner) else None
+                check(f"first-layer exchange, width {width}", got[lp.n_own:].ravel(), want[lp.n_own:].ravel(), part_of_ghost)
+            dp = self.deep
+            if dp is not None:
+                v = np.full(dp.n_ext, -1.0)
+                v[: dp.n_own] = f(dp.ext_to_global[: dp.n_own])
+                got = ctx.comm_test_halo(v, width=1, deep=True)
+                who = np.full(dp.n_ext, -1)
+                for nb, idx in dp.recv_idx.items():
+                    who[idx] = nb
+                check("deep exchange of the residual", got[dp.n_own:], f(dp.ext_to_global[dp.n_own:]), who[dp.n_own:])
+            x = np.arange(3072, dtype=np.float64) + 1000.0 * (self.rank + 1)
+            check("sum of 3 x 1024 partials", ctx.comm_test_allreduce(x), np.arange(3072.0) * w + 1000.0 * w * (w + 1) / 2, None)
+            check("maximum", ctx.comm_test_allreduce(np.array([float(self.rank), -float(self.rank)]), op="max"),
+                  np.array([float(w - 1), 0.0]), None)
+            n2 = 20000 if dp is None else int(dp.M.shape[0])
+            y = (np.arange(n2) % 257).astype(np.float64) + self.rank  # small integers: exact in fp32
+            check("level-2-sized sum carried as fp32", ctx.comm_test_allreduce(y, as_f32=True),
+                  (np.arange(n2) % 257) * float(w) + w * (w - 1) / 2, None)
+            report["ok"] = all(c["ok"] for c in report["checks"])
+        except Exception as exc:  # a transport error (RCCL, a peer that never answered): report it
+            report["ok"] = False
+            report["error"] = f"{type(exc).__name__}: {exc}"
+        return report
 
     # -- inputs -----------------------------------------------------------------------------------
     def set_mu_boundary(self, mu_boundary_global):

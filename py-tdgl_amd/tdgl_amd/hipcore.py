@@ -351,6 +351,30 @@ class TDGLContext:
         assert len(unique_id) == 128
         self._chk(self._lib.tdgl_comm_init_rccl(self._ctx, C.c_char_p(unique_id)))
 
+    def comm_ipc_export(self, world: int):
+        """``(handle: 64 bytes, table: int64[4 + 6 world])`` of this rank's inbox (`tdgl_comm_ipc_export`)."""
+        handle = C.create_string_buffer(64)
+        table = np.zeros(4 + 6 * int(world), dtype=np.int64)
+        self._chk(self._lib.tdgl_comm_ipc_export(self._ctx, handle, table.ctypes.data_as(_lib.c_i64p), len(table)))
+        return handle.raw, table
+
+    def comm_init_ipc(self, handles, tables):
+        """``handles``: the ranks' 64-byte handles in rank order, ``tables``: their tables (`tdgl_comm_init_ipc`)."""
+        blob = b"".join(handles)
+        tab = np.ascontiguousarray(np.stack(tables), dtype=np.int64)
+        self._chk(self._lib.tdgl_comm_init_ipc(self._ctx, C.c_char_p(blob), tab.ctypes.data_as(_lib.c_i64p)))
+
+    def comm_test_halo(self, vec, width=1, deep=False):
+        """One exchange of ``vec``'s ghost entries through the context's transport (`tdgl_comm_test_halo`)."""
+        v = np.ascontiguousarray(vec, dtype=np.float64).copy()
+        self._chk(self._lib.tdgl_comm_test_halo(self._ctx, p_f64(v), int(width), int(bool(deep))))
+        return v
+
+    def comm_test_allreduce(self, buf, op="sum", as_f32=False):
+        v = np.ascontiguousarray(buf, dtype=np.float64).copy()
+        self._chk(self._lib.tdgl_comm_test_allreduce(self._ctx, p_f64(v), v.size, 0 if op == "sum" else 1, int(bool(as_f32))))
+        return v
+
     def comm_init_callbacks(self, halo, allreduce):
         """``halo(send, send_off, recv, recv_off, ranks)`` and ``allreduce(buf, op)`` operate on
         NumPy views of the library's pinned host buffers (test transport)."""

@@ -103,11 +103,14 @@ def _single_gpu_reference(size=(60, 15), problem_kw=None, want_ctx=False):
     return mesh, res, ctx.get_state()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multi_rank_run_matches_single_gpu(world, tmp_path):
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (2, "ipc"), (3, "ipc")])
+def test_multi_rank_run_matches_single_gpu(world, transport, tmp_path):
+    """transport "ipc": the peer-mapped transport of csrc/ipc.inc -- the ranks' kernels store straight into each
+    other's hipIpc-mapped inboxes and poll flags there, everything on one stream; here the processes share one GPU,
+    on a node they sit on peers."""
     mesh, ref_res, ref = _single_gpu_reference()
-    mp.spawn(_worker, args=(world, _free_port(), "gloo", str(tmp_path)), nprocs=world, join=True)
-    got = np.load(os.path.join(tmp_path, f"dist_gloo_{world}.npz"))
+    mp.spawn(_worker, args=(world, _free_port(), transport, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"dist_{transport}_{world}.npz"))
     # same algorithm, same tolerances; only the summation order of the dot products differs
     assert len(got["dt"]) == N_STEPS
     assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
@@ -176,6 +179,21 @@ def test_halo_overlap_on_second_stream_matches_single_gpu(overlap, tmp_path):
     assert np.abs(got["normal_current"] - ref["normal_current"]).max() < 1e-9
 
 
+def test_peer_mapped_transport_overlaps_at_any_size(tmp_path):
+    """With the peer-mapped transport an exchange is a sending and a receiving launch on the compute stream; the
+    ghost-free tiles of the consumer are queued between them whatever the size of the partition (with RCCL the two
+    cross-stream dependencies of an overlapped exchange cost 21 us: automatic mode waits for 750k ghost-free rows)."""
+    size = (120, 120)
+    mesh, ref_res, ref = _single_gpu_reference(size)
+    mp.spawn(_worker, args=(3, _free_port(), "ipc", str(tmp_path), "auto", size), nprocs=3, join=True)
+    got = np.load(os.path.join(tmp_path, "dist_ipc_3.npz"))
+    assert bool(got["overlap"]) and not bool(got["deep"])
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-9
+    assert np.abs(got["mu"] - ref["mu"]).max() < 1e-9 * max(1.0, np.abs(ref["mu"]).max())
+    assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-9
+
+
 def test_eight_ranks_match_single_gpu(tmp_path):
     """The node size of the scaling runs: 8 ranks (here sharing one GPU through the callback
     transport), 2x4 RCB blocks with up to 5 neighbours per rank, corner-only contacts included."""
@@ -195,7 +213,7 @@ def test_eight_ranks_match_single_gpu(tmp_path):
 DEEP_KW = dict(deep=True, max_coarse=50, plan_kw=dict(tail_rows=1200, dense_rows=400))
 
 
-@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (8, "gloo"), (1, "rccl")])
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (8, "gloo"), (1, "rccl"), (2, "ipc"), (3, "ipc"), (8, "ipc")])
 def test_two_distributed_levels_match_single_gpu(world, transport, tmp_path):
     """The decomposition the scaling run uses from ~30k sites per job on (forced here on a 16k-site film by making
     level 1 an intermediate level of the collapsed chain): per-rank aggregates, level 1 distributed through its
