@@ -243,7 +243,7 @@ def self_launch(args, argv):
     from tdgl_amd import _lib as _tdgl_lib
 
     have = _tdgl_lib.device_count()
-    if have < args.gpus and args.transport == "rccl":
+    if have < args.gpus and not (args.share_devices or args.transport == "gloo"):
         print(json.dumps(dict(metric=METRIC, value=None, unit="steps/s", n_gpus=args.gpus, steps=args.steps,
                               warmup=args.warmup, higher_is_better=True,
                               error=f"needs {args.gpus} devices, found {have}")), flush=True)
@@ -316,10 +316,19 @@ def main():
     ap.add_argument("--late-steps", type=int, default=6000,
                     help="steps after the vortex window before a third timed window in the long-time regime (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--transport", choices=["rccl", "gloo"], default="rccl",
-                    help="decomposed runs: rccl = one GPU per rank, exchanges inside tdgl_run over RCCL (the product path); "
-                         "gloo = host callbacks + torch.distributed, all ranks may share ONE GPU (a dry run of the decomposition: "
-                         "message counts and sizes are real, timings are not)")
+    ap.add_argument("--transport", choices=["auto", "ipc", "rccl", "gloo"], default="auto",
+                    help="decomposed runs, one GPU per rank: ipc = peer-mapped inboxes, neighbours' kernels store into each other's "
+                         "memory over xGMI (csrc/ipc.inc); rccl = ncclSend/Recv + ncclAllReduce; auto (default) = ipc if its self-test "
+                         "passes on every rank, else rccl if ITS self-test passes, else an error line.  gloo = host callbacks + "
+                         "torch.distributed (a dry run: message counts and sizes are real, timings are not; implies --share-devices)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="let the ranks share the visible GPUs (rank r on device r %% count): a dry run of the decomposition on a "
+                         "box with fewer GPUs than ranks -- works with --transport ipc and gloo")
+    ap.add_argument("--transport-timeout", type=int, default=240,
+                    help="seconds a transport candidate may take to set up, pass its self-test and take the probe steps")
+    ap.add_argument("--selftest", choices=["on", "off"], default="on",
+                    help="decomposed runs: before anything is timed, one exchange per pattern and one sum per kind through the "
+                         "transport, checked entry by entry on every rank (DistributedTDGL.selftest); the line carries the report")
     ap.add_argument("--dist-levels", type=int, choices=[1, 2], default=2,
                     help="decomposed runs: 2 (default) = levels 0 and 1 of the AMG hierarchy distributed, one vector exchange "
                          "per PCG iteration (partition.DeepPlanner); 1 = level 0 only, everything below replicated (rounds 1-4)")
@@ -343,7 +352,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.transport == "gloo":  # dry run: every rank on the devices there are
+    share = args.share_devices or args.transport == "gloo"
+    if share:  # dry run: every rank on the devices there are
         from tdgl_amd import _lib as _probe
 
         local_rank %= max(1, _probe.device_count())
@@ -375,6 +385,9 @@ def main():
                 precond_fp32=(False if args.precond_fp64 else 1 if args.precond_fp32 else True), collapse=not args.no_collapse, tail_cycles=args.tail_cycles,
                 guess_window=args.guess_window, flexible_cg=args.cg_flexible)
 
+    selftests, chosen_transport = {}, {}
+    PROBE_STEPS = 40  # steps a transport candidate takes before the choice (they are the first steps of the pre-roll)
+
     def run_workload(name, want_cpu_state):
         """Set up `name`, pre-roll + warm up, time K steps.  Returns a dict of measurements (rank 0
         holds the global mesh; in decomposed runs the other ranks receive their pieces from it)."""
@@ -382,7 +395,7 @@ def main():
         wl = build_workload(name) if (rank == 0 or not use_dd) else None
         if wl is not None and wl.strip and use_dd:
             raise SystemExit("the strip workload is single-GPU in bench.py")
-        drun = None
+        drun, probed = None, False
         if not use_dd:
             solver = TDGLSolver.from_dimensionless(wl.mesh, opts, wl.A, 1.0, terminal_info=wl.terms, current_func=wl.currents,
                                                    probe_points=None if args.no_probes else wl.probes)
@@ -396,12 +409,84 @@ def main():
             # the AMG hierarchy once and scatters the pieces.
             from tdgl_amd.distributed import DistributedTDGL
 
-            drun = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
-                                   rank=rank, world=world, transport=args.transport, device_id=local_rank, root=0,
-                                   deep="auto" if args.dist_levels == 2 else False)
+            # Transport.  Every candidate ("auto": the peer-mapped one, then RCCL) is set up inside a watchdog thread (a
+            # hung collective blocks inside a library, where no Python handler runs: the thread is then abandoned and
+            # the candidate counts as failed on every rank), must pass the self-test on every rank, and -- if more than
+            # one is in the race -- takes the first PROBE_STEPS steps of the pre-roll with a clock on the second half:
+            # the fastest one continues, the others are closed.  All decisions are taken on what EVERY rank reports.
+            import threading
+
+            candidates = ["ipc", "rccl"] if args.transport == "auto" else [args.transport]
+            if world == 1 and args.transport == "auto":
+                candidates = ["rccl"]  # (--force-distributed on one rank: the communicator path, as in rounds 1-4)
+            payload, alive = None, {}
+            for tr in candidates:
+                box = {}
+
+                def attempt(tr=tr, box=box, payload=payload):
+                    try:
+                        d = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
+                                            rank=rank, world=world, transport=tr, device_id=local_rank, root=0,
+                                            deep="auto" if args.dist_levels == 2 else False, payload=payload)
+                        box["drun"] = d
+                        rep = d.selftest() if (args.selftest == "on" and world > 1) else dict(ok=True, skipped=True)
+                        box["rep"] = rep
+                        if rep["ok"] and len(candidates) > 1:
+                            d.set_state(1.0, 0.0)
+                            d.ctx.set_poisson_options(**popt)
+                            d.ctx.begin_stage()
+                            d.ctx.run(PROBE_STEPS // 2)
+                            d.ctx.synchronize()
+                            t1 = time.perf_counter()
+                            d.ctx.run(PROBE_STEPS - PROBE_STEPS // 2)
+                            d.ctx.synchronize()
+                            box["probe_steps_per_s"] = (PROBE_STEPS - PROBE_STEPS // 2) / (time.perf_counter() - t1)
+                    except Exception as exc:
+                        box["error"] = f"{type(exc).__name__}: {exc}"
+
+                if payload is None:  # the first candidate receives this rank's piece over the bootstrap group: main thread
+                    attempt()
+                    finished = True
+                else:
+                    th = threading.Thread(target=attempt, daemon=True)
+                    th.start()
+                    th.join(args.transport_timeout)
+                    finished = not th.is_alive()
+                if box.get("drun") is not None and payload is None:
+                    payload = box["drun"].payload  # (the next candidate reuses the piece this rank already received)
+                rep = dict(box.get("rep") or dict(ok=False))
+                if not finished:
+                    rep.update(ok=False, error=f"did not finish within {args.transport_timeout} s (abandoned)")
+                elif "error" in box:
+                    rep.update(ok=False, error=box["error"])
+                rep.update(transport=tr, device=local_rank, probe_steps_per_s=box.get("probe_steps_per_s"))
+                reports = [rep]
+                if world > 1:
+                    reports = [None] * world
+                    dist.all_gather_object(reports, rep)
+                ok = all(x["ok"] for x in reports)
+                sps = [x.get("probe_steps_per_s") for x in reports]
+                selftests.setdefault(name, []).append(dict(
+                    transport=tr, ok=ok, probe_steps_per_s=None if (not ok or None in sps) else round(min(sps), 1), ranks=reports))
+                if ok:
+                    alive[tr] = box["drun"]
+                else:
+                    log(f"rank {rank}: transport {tr} is out: " + json.dumps([x for x in reports if not x["ok"]])[:2000])
+                    if finished and box.get("drun") is not None:
+                        box["drun"].close()
+            if not alive:
+                raise RuntimeError("no transport passed its self-test: " + json.dumps(selftests[name])[:4000])
+            rates = {t["transport"]: (t["probe_steps_per_s"] or 0.0) for t in selftests[name] if t["transport"] in alive}
+            best = max(alive, key=lambda tr: rates[tr])
+            for tr, d in alive.items():
+                if tr != best:
+                    d.close()
+            drun, chosen_transport[name] = alive[best], best
+            probed = len(candidates) > 1
             ctx = drun.ctx
             n_loc, m_loc, n, m = drun.lp.n_own, len(drun.lp.edge_local_to_global), drun.n_global, drun.m_global
-            drun.set_state(1.0, 0.0)
+            if not probed:
+                drun.set_state(1.0, 0.0)
             log(f"rank {rank}: owns {n_loc} sites, {drun.lp.n_ghost} ghosts, neighbours {drun.lp.neighbors}")
         ctx.set_poisson_options(**popt)
         h = ctx.hierarchy
@@ -423,7 +508,8 @@ def main():
             setup["mu_solver"] = "amg_pcg"
         log(f"rank {rank}: {name} set-up {total_s:.1f} s {setup}; AMG levels {h.sizes}, "
             f"operator complexity {h.operator_complexity:.2f}")
-        ctx.begin_stage()
+        if not probed:
+            ctx.begin_stage()
 
         def barrier():
             ctx.synchronize()
@@ -431,7 +517,10 @@ def main():
                 dist.barrier()
 
         trace = []
-        if args.preroll > 0:
+        if probed:  # (the probe steps of the transport race were the first steps of the pre-roll)
+            if args.preroll > PROBE_STEPS:
+                trace.append(ctx.run(args.preroll - PROBE_STEPS))
+        elif args.preroll > 0:
             trace.append(ctx.run(args.preroll))
         if args.warmup > 0:
             trace.append(ctx.run(args.warmup))
@@ -654,6 +743,15 @@ def main():
             ),
         )
         if use_dd:  # what rank 0 exchanged per step (every rank issues the same sequence)
+            st = selftests.get(r.name, [])
+            d["transport"] = dict(
+                used=chosen_transport.get(r.name),
+                # one exchange per pattern + one sum per kind, checked entry by entry on every rank before anything was timed
+                selftest=[dict(transport=t["transport"], ok=t["ok"], probe_steps_per_s=t.get("probe_steps_per_s"),
+                               checks_per_rank=len(t["ranks"][0].get("checks", [])),
+                               failures=[dict(rank=x.get("rank"), error=x.get("error"),
+                                              bad=[c for c in x.get("checks", []) if not c["ok"]][:3])
+                                         for x in t["ranks"] if not x["ok"]][:8]) for t in st])
             d["comm_per_step"] = dict(
                 halo_exchanges=round(r.comm["halos"] / args.steps, 1),
                 halo_bytes_sent=int(r.comm["halo_bytes"] / args.steps),
@@ -747,8 +845,10 @@ def main():
             sites=r.n, edges=r.m, amg_levels=r.sizes, preroll=args.preroll,
             parallelism="single" if world == 1 else
             f"domain decomposition (RCB, {world} ranks, ~{r.n // world} sites each), "
-            + ("RCCL halo exchange + all-reduce" if args.transport == "rccl" else
-               "DRY RUN: host-callback transport, ranks share the visible GPUs -- counts and sizes of the exchanges are real, the timing is not"),
+            + {"rccl": "RCCL halo exchange (ncclSend/Recv) + ncclAllReduce",
+               "ipc": "peer-mapped transport: neighbours' kernels store into each other's hipIpc-mapped inboxes, flags polled in-kernel, one stream",
+               "gloo": "host-callback transport"}[chosen_transport.get(args.workload, args.transport)]
+            + ("; DRY RUN: the ranks share the visible GPUs -- counts and sizes of the exchanges are real, the timing is not" if share else ""),
         ),
         roofline=main_line["roofline"],
         roofline_pcg=roofline_pcg,
@@ -770,6 +870,7 @@ def main():
         out["sustained"] = getattr(main_run, "sustained", None)
     if rank == 0 and "comm_per_step" in main_line:
         out["comm_per_step"] = main_line["comm_per_step"]
+        out["transport"] = main_line.get("transport")
     # BASELINE config 5 next to the headline workload (decomposed runs).  The headline measurement is
     # complete at this point: a watchdog thread prints it if the second workload does not finish in
     # time (a hung collective blocks inside the library, where no Python signal handler runs), so the

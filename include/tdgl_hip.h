@@ -371,6 +371,8 @@ typedef struct {
     const int32_t *send_idx;         /* owned local ids */
     const int32_t *recv_ptr;         /* [n_neighbors + 1] */
     const int32_t *recv_idx;         /* ghost local ids in [n_owned, n_ext) */
+    int64_t l1_interior;             /* leading level-1 rows whose restriction b1 = F r reads owned fine entries only:
+                                        formed while the exchange is in flight (peer-mapped transport) */
 } tdgl_deep_halo_plan;
 int tdgl_set_deep_halo_plan(tdgl_ctx *ctx, const tdgl_deep_halo_plan *plan);
 /* RCCL transport (xGMI): rank 0 makes the 128-byte id, the host layer broadcasts it, every rank

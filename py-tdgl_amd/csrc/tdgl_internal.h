@@ -234,6 +234,7 @@ struct tdgl_ctx {
     // two distributed AMG levels (tdgl_set_deep_halo_plan): the exchange of r on the whole ghost zone
     bool deep = false;
     int64_t n_ext = 0;        // owned + every ghost layer (length of the PCG's level-0 vectors)
+    int64_t l1_interior = 0;  // leading level-1 rows whose restriction reads owned fine entries only
     std::vector<int32_t> deep_nbrs, deep_send_ptr, deep_recv_ptr;
     tdgl::DevBuf<int32_t> d_deep_send_idx, d_deep_recv_idx;
     tdgl::DevBuf<double> d_deep_sendbuf, d_deep_recvbuf;

