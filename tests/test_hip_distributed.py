@@ -248,6 +248,50 @@ def test_transport_selftest_passes_and_names_a_broken_neighbour(transport, tmp_p
             assert failing and all("deep" in c["name"] for c in failing) and all(c["owner"] == 1 for c in failing)
 
 
+def _dying_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem()
+    from tdgl_amd import _lib  # noqa: F401
+
+    _lib.load()
+    import time
+
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdgl_amd.distributed import DistributedTDGL
+
+        run = DistributedTDGL(mesh, opts, A, 1.0, rank=rank, world=world, terminal_info=terms, mu_boundary=mu_b,
+                              transport="ipc", device_id=0)
+        run.set_state(psi0, np.zeros(len(mesh.sites)))
+        run.begin_stage()
+        run.run(3)  # both ranks alive: fine
+        dist.barrier()
+        if rank == 1:
+            return  # leaves the collective sequence: its partner's next wait can never be satisfied
+        t0 = time.perf_counter()
+        try:
+            run.run(3)
+            outcome = "no error"
+        except RuntimeError as exc:
+            outcome = str(exc)
+        with open(os.path.join(out_dir, "dying.txt"), "w") as f:
+            f.write(f"{time.perf_counter() - t0:.1f}\n{outcome}\n")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_mapped_transport_turns_a_dead_rank_into_an_error_not_a_hang(tmp_path):
+    """Waits of the peer-mapped transport are bounded (8 s): when a rank leaves, its neighbour's next exchange times
+    out ONCE, every later wait of that context returns at once, and `run` raises at its end -- the box is never left
+    with a kernel that spins for good."""
+    mp.spawn(_dying_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    seconds, outcome = open(os.path.join(tmp_path, "dying.txt")).read().split("\n")[:2]
+    assert "did not arrive within 8 s" in outcome
+    assert 7.0 < float(seconds) < 20.0
+
+
 def test_eight_ranks_match_single_gpu(tmp_path):
     """The node size of the scaling runs: 8 ranks (here sharing one GPU through the callback
     transport), 2x4 RCB blocks with up to 5 neighbours per rank, corner-only contacts included."""
