@@ -177,6 +177,12 @@ struct StepCtl {
     int hist_count;
     int pad;
     double hist[RA_HIST_MAX];  // the last min(window, count) values of max d|psi|^2, oldest first
+    // field ramp evaluated inside the loop (k_ra_ramp_begin): A(t) = ramp(t) A_base
+    double runner_dt;          // Runner.dt: dt of the previous accepted step (the dA/dt of this one divides by it)
+    double ramp_tmin, ramp_tmax, ramp_initial, ramp_final;
+    double link_scale, link_scale_prev;
+    int has_dadt;              // a dynamic update has run (update_link_scale's early return needs one)
+    int ramp_do;               // this attempt is the first of a step and the vector potential moves
 };
 struct StepRec {
     double dt, dmax;
