@@ -1,0 +1,55 @@
+"""`bench.py` as the driver calls it, end to end (GPU): the decomposed path with its transport race and self-test on
+ranks that share the test box's one GPU, and the single-GPU line's contract fields."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*flags, timeout=600):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_two_ranks_sharing_the_gpu_race_the_transports_and_report_it():
+    """`--gpus 2 --share-devices` (what the driver runs with one GPU per rank, here oversubscribed): the peer-mapped
+    transport passes its self-test on both ranks, RCCL refuses two ranks on one device and is recorded as out, the
+    line says which transport ran, what a step communicated, and that the timing is a dry run."""
+    d = _run("--gpus", "2", "--share-devices", "--workload", "250k", "--steps", "10", "--warmup", "5", "--preroll", "60",
+             "--no-cpu-baseline", "--config5", "off")
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "strong" and d["value"] > 0
+    tr = d["transport"]
+    assert tr["used"] == "ipc"
+    by = {t["transport"]: t for t in tr["selftest"]}
+    assert by["ipc"]["ok"] and by["ipc"]["checks_per_rank"] >= 5 and by["ipc"]["probe_steps_per_s"] > 0
+    assert not by["rccl"]["ok"] and by["rccl"]["failures"]
+    c = d["comm_per_step"]
+    assert "levels 0 and 1 distributed" in c["decomposition"] and c["overlap"] is True
+    its = d["pcg"]["mean_iterations"]
+    assert c["halo_exchanges"] <= 1.3 * its + 3.5 and c["deep_ghost_entries"] > c["ghost_sites"]
+    assert "DRY RUN" in d["config"]["parallelism"] and "peer-mapped" in d["config"]["parallelism"]
+
+
+def test_single_gpu_line_carries_the_contract_fields():
+    d = _run("--workload", "60k", "--steps", "20", "--warmup", "5", "--preroll", "40", "--cpu-seconds", "2", "--vortex-window", "off")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["frac_net"] >= r["frac"] and r["frac_burst"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    assert d["parity_vs_oracle"]["ok"] and d["parity_vs_oracle"]["tolerance"] == 1e-8
