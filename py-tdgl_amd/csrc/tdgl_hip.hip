@@ -545,7 +545,7 @@ static inline int guess_grid(const tdgl_ctx *ctx) { return std::min(ctx->npart, 
 // one process per GPU with at most G_RANK_STRIDE ranks: the ranks' double-double totals are gathered exactly
 static inline bool guess_rank_totals(const tdgl_ctx *ctx) {
     static const bool off = getenv("TDGL_GUESS_NO_GATHER") != nullptr;  // (tests: the path of more than 16 ranks)
-    return (ctx->world > 1 || ctx->comm != nullptr) && ctx->world <= G_RANK_STRIDE && !off;
+    return (ctx->world > 1 || ctx->comm != nullptr || ctx->ipc != nullptr) && ctx->world <= G_RANK_STRIDE && !off;
 }
 
 static void publish_status(tdgl_ctx *ctx, bool guess_start = false, const double *rr_part = nullptr) {

@@ -217,7 +217,7 @@ class DistributedTDGL:
         if self.deep is not None:
             ctx.set_deep_halo_plan(self.deep)
         ctx.set_comm_overlap(overlap)  # halo exchanges hidden behind the ghost-free rows
-        if self.world > 1 or transport == "rccl":
+        if self.world > 1 or transport in ("rccl", "ipc"):  # (one rank: the decomposed sequence with world = 1)
             if transport == "rccl":
                 ident = [ctx.comm_unique_id() if self.rank == 0 else None]
                 dist.broadcast_object_list(ident, src=0)

@@ -311,7 +311,7 @@ def test_eight_ranks_match_single_gpu(tmp_path):
 DEEP_KW = dict(deep=True, max_coarse=50, plan_kw=dict(tail_rows=1200, dense_rows=400))
 
 
-@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (8, "gloo"), (1, "rccl"), (2, "ipc"), (3, "ipc"), (8, "ipc")])
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (8, "gloo"), (1, "rccl"), (1, "ipc"), (2, "ipc"), (3, "ipc"), (8, "ipc")])
 def test_two_distributed_levels_match_single_gpu(world, transport, tmp_path):
     """The decomposition the scaling run uses from ~30k sites per job on (forced here on a 16k-site film by making
     level 1 an intermediate level of the collapsed chain): per-rank aggregates, level 1 distributed through its
