@@ -677,13 +677,13 @@ class TDGLContext:
         precond_fp32 = precond_storage_mode(precond_fp32)
         o = _lib.PoissonOptions(float(rtol), int(max_iter), int(nu), int(check_every),
                                 int(bool(edge_currents_every_step)), kind, float(cheb_lo),
-                                int(extrapolate), int(nu_fine), precond_fp32, int(guess_window), int(bool(flexible_cg)))
+                                int(extrapolate), int(nu_fine), precond_fp32, int(guess_window), int(flexible_cg))
         self.poisson_options = dict(rtol=rtol, max_iter=max_iter, nu=nu, nu_fine=nu_fine, check_every=check_every,
                                     smoother=kind, cheb_lo=cheb_lo, extrapolate=int(extrapolate),
                                     fused_restriction=bool(fused_restriction), precond_fp32=precond_fp32,
                                     edge_currents_every_step=bool(edge_currents_every_step),
                                     collapse=bool(collapse), tail_cycles=int(tail_cycles),
-                                    guess_window=int(guess_window), flexible_cg=bool(flexible_cg))
+                                    guess_window=int(guess_window), flexible_cg=int(flexible_cg))
         self._chk(self._lib.tdgl_set_poisson_options(self._ctx, C.byref(o)))
         self._refresh_fused_restriction()
         self._refresh_collapsed()
