@@ -292,6 +292,48 @@ def test_peer_mapped_transport_turns_a_dead_rank_into_an_error_not_a_hang(tmp_pa
     assert 7.0 < float(seconds) < 20.0
 
 
+def _soak_worker(rank, world, port, transport, out_dir, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mesh, terms, A, mu_b, opts, probes, psi0 = _problem(120, 120, dt_init=1e-3, dt_max=0.5, b=0.6)
+    from tdgl_amd import _lib  # noqa: F401
+
+    _lib.load()
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdgl_amd.distributed import DistributedTDGL
+
+        run = DistributedTDGL(mesh, opts, A, 1.0, rank=rank, world=world, terminal_info=terms, mu_boundary=mu_b,
+                              transport=transport, device_id=0, **DEEP_KW)
+        run.set_state(psi0, np.zeros(len(mesh.sites)))
+        run.begin_stage()
+        res = run.run(steps)
+        fields = run.gather_state()
+        if rank == 0:
+            np.savez(os.path.join(out_dir, f"soak_{transport}.npz"), dt=res["dt"], iters=res["pcg_iters"],
+                     retries=run.ctx.step_stats()["psi_retries"], **fields)
+        run.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_mapped_transport_is_bit_identical_to_the_host_transport_over_a_long_run(tmp_path):
+    """A race detector for the transport's ordering (payload and flags are write-through stores drained before the
+    flag, no fences: csrc/ipc.inc).  On TWO ranks every sum over ranks is a + b, whatever the transport, so the
+    peer-mapped run must reproduce the host-callback run BIT FOR BIT -- dt sequence, iteration counts, fields -- over
+    600 steps with vortex entry and dt retries (~25,000 exchanges and sums); one stale value anywhere would show."""
+    steps = 600
+    for transport in ("gloo", "ipc"):
+        mp.spawn(_soak_worker, args=(2, _free_port(), transport, str(tmp_path), steps), nprocs=2, join=True)
+    a, b = (np.load(os.path.join(tmp_path, f"soak_{t}.npz")) for t in ("gloo", "ipc"))
+    assert len(a["dt"]) == steps and int(a["retries"]) > 0 and a["iters"].sum() > 3000
+    assert np.array_equal(a["dt"], b["dt"]) and np.array_equal(a["iters"], b["iters"]) and int(a["retries"]) == int(b["retries"])
+    for key in ("psi", "mu", "supercurrent", "normal_current"):
+        assert np.array_equal(a[key], b[key]), key
+    assert (np.abs(a["psi"]) ** 2).min() < 0.5  # vortices are in
+
+
 def test_eight_ranks_match_single_gpu(tmp_path):
     """The node size of the scaling runs: 8 ranks (here sharing one GPU through the callback
     transport), 2x4 RCB blocks with up to 5 neighbours per rank, corner-only contacts included."""
