@@ -502,6 +502,8 @@ def main():
         st = dict(getattr(ctx, "setup_times", {}))
         setup = dict(mesh=round(wl.mesh_s, 2) if wl is not None else None, reorder=round(st.get("reorder", 0.0), 2),
                      amg_host=round(st.get("amg_host", 0.0), 2), upload=round(st.get("upload", 0.0), 2), total=round(total_s, 2))
+        if st.get("amg_candidates"):  # hierarchies built and probed on the device; the one with the smallest contraction stayed
+            setup["amg_candidates"] = st["amg_candidates"]
         sub = getattr(ctx, "substructure", None)
         if sub:  # mid-size meshes: substructured direct solve, factors formed on the device
             setup["substructure"] = dict(host=round(st.get("substructure_host", 0.0), 2), device=round(st.get("substructure_device", 0.0), 2),

@@ -342,3 +342,30 @@ def test_seed_solution_read_back_from_the_output_file_continues_the_run(tmp_path
     other.name = "another"
     with pytest.raises(ValueError, match="seed_solution.device must be equal"):
         tdgl.solve(other, tdgl.SolverOptions(solve_time=half, **kw), seed_solution=seed)
+
+
+def test_hierarchy_candidates_are_probed_and_the_best_one_stays():
+    """`TDGLContext.build_poisson(amg_candidates=3)`: the hashed priorities of the MIS(2) aggregation give hierarchies
+    that differ by luck (at 1M sites 7.50 to 7.79 PCG iterations per step); three are built, each solves one fixed
+    pseudo-random right-hand side on the device, the smallest contraction per iteration stays on the device."""
+    from helpers import synthetic_mesh
+    from tdgl_amd.hipcore import TDGLContext
+
+    mesh = synthetic_mesh(120, 100)
+    ctx = TDGLContext(mesh, direct_solve=False)
+    h = ctx.build_poisson(rtol=1e-10, amg_candidates=3)
+    scores = ctx.setup_times["amg_candidates"]
+    assert [s["seed"] for s in scores] == [0, 1, 2] and len({tuple(s["sizes"]) for s in scores}) >= 2
+    best = min(scores, key=lambda s: s["contraction"])
+    assert h.sizes == best["sizes"] and ctx.hierarchy.sizes == best["sizes"]
+    assert all(0.05 < s["contraction"] < 0.6 and s["relres"] <= 1e-10 for s in scores)
+    rng = np.random.default_rng(1)
+    rhs = rng.standard_normal(len(mesh.sites)) / mesh.areas
+    rhs -= (rhs * mesh.areas).sum() / mesh.areas.sum()
+    _, its, relres = ctx.poisson_solve(rhs)
+    assert relres <= 1e-10 and abs(its - best["iterations"]) <= 2
+    # one candidate: nothing is probed
+    ctx2 = TDGLContext(mesh, direct_solve=False)
+    ctx2.build_poisson(amg_candidates=1)
+    assert "amg_candidates" not in ctx2.setup_times
+    ctx.close(); ctx2.close()
