@@ -123,14 +123,16 @@ def test_multi_rank_run_matches_single_gpu(world, transport, tmp_path):
     assert abs(got["iters"].mean() - ref_res["pcg_iters"].mean()) < 2.0
 
 
-def test_more_ranks_than_the_exact_gather_holds(tmp_path, monkeypatch):
+@pytest.mark.parametrize("transport", ["gloo", "ipc"])
+def test_more_ranks_than_the_exact_gather_holds(transport, tmp_path, monkeypatch):
     """Beyond 16 ranks the guess's double-double totals are not gathered rank by rank: hi and lo parts are
     all-reduced separately (fp64 accuracy) and the pivot threshold of the small solve is raised to 1e-13.
     Forced here on 2 ranks: same trajectory, at most a few more iterations."""
     monkeypatch.setenv("TDGL_GUESS_NO_GATHER", "1")
     mesh, ref_res, ref = _single_gpu_reference()
-    mp.spawn(_worker, args=(2, _free_port(), "gloo", str(tmp_path)), nprocs=2, join=True)
-    got = np.load(os.path.join(tmp_path, "dist_gloo_2.npz"))
+    # (peer-mapped transport: these sums are 28k doubles long, more than one inbox slot holds -- they travel in pieces)
+    mp.spawn(_worker, args=(2, _free_port(), transport, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(tmp_path, f"dist_{transport}_2.npz"))
     assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
     assert np.abs(got["mu"] - ref["mu"]).max() < 1e-9 * max(1.0, np.abs(ref["mu"]).max())
     assert got["iters"].mean() < ref_res["pcg_iters"].mean() + 4.0
@@ -383,7 +385,7 @@ def test_two_distributed_levels_match_single_gpu(world, transport, tmp_path):
         assert int(got["allreduce_bytes"]) <= 1.15 * its * (4 * n_level2 + 3 * 8192) + N_STEPS * 60000
 
 
-def _screening_worker(rank, world, port, out_dir):
+def _screening_worker(rank, world, port, out_dir, transport="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for p in (ROOT, os.path.join(ROOT, "py-tdgl_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -409,7 +411,7 @@ def _screening_worker(rank, world, port, out_dir):
             screening_step_size=float(g["opt_screening_step_size"]), screening_step_drag=float(g["opt_screening_step_drag"]),
         )
         run = DistributedTDGL(
-            mesh, opts, uniform_field_A(mesh, float(g["b"])), 1.0, rank=rank, world=world, transport="gloo", device_id=0,
+            mesh, opts, uniform_field_A(mesh, float(g["b"])), 1.0, rank=rank, world=world, transport=transport, device_id=0,
             screening=dict(sites=mesh.sites, edge_centers=mesh.edge_mesh.centers,
                            areas=float(g["screening_scale"]) * mesh.areas),
         )
@@ -424,15 +426,15 @@ def _screening_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_screening_on_several_ranks_matches_the_reference_fixture(world, tmp_path):
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (3, "ipc")])
+def test_screening_on_several_ranks_matches_the_reference_fixture(world, transport, tmp_path):
     """include_screening in one-process-per-GPU mode: the site currents of all ranks are summed
     into a global array per screening iteration; against the REFERENCE's trajectory (fixture
     traj_screening_tiny): same screening iteration counts, same fields, same A_induced."""
     from conftest import load_golden
 
     g = load_golden("traj_screening_tiny")
-    mp.spawn(_screening_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_screening_worker, args=(world, _free_port(), str(tmp_path), transport), nprocs=world, join=True)
     got = np.load(os.path.join(tmp_path, f"scr_{world}.npz"))
     assert np.array_equal(got["iters"], g["call_screening_iterations"])
     assert np.abs(got["dt"] - g["call_dt"]).max() <= 1e-9 * g["call_dt"].max()
