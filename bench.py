@@ -327,6 +327,7 @@ def main():
     ap.add_argument("--transport-timeout", type=int, default=240,
                     help="seconds a transport candidate may take to set up, pass its self-test and take the probe steps")
     ap.add_argument("--debug-pre", default="none", help=argparse.SUPPRESS)
+    ap.add_argument("--debug-fail", default="", help=argparse.SUPPRESS)  # transports made to fail (tests of the fall-back)
     ap.add_argument("--selftest", choices=["on", "off"], default="on",
                     help="decomposed runs: before anything is timed, one exchange per pattern and one sum per kind through the "
                          "transport, checked entry by entry on every rank (DistributedTDGL.selftest); the line carries the report")
@@ -425,6 +426,7 @@ def main():
             import threading
 
             candidates = ["ipc", "rccl"] if args.transport == "auto" else [args.transport]
+            last_resort = "gloo" if args.transport == "auto" else None  # (host callbacks: slow, but a line rather than none)
             if world == 1 and args.transport == "auto":
                 candidates = ["rccl"]  # (--force-distributed on one rank: the communicator path, as in rounds 1-4)
             payload, alive = None, {}
@@ -433,6 +435,8 @@ def main():
 
                 def attempt(tr=tr, box=box, payload=payload):
                     try:
+                        if tr in args.debug_fail.split(","):
+                            raise RuntimeError("made to fail (--debug-fail)")
                         d = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
                                             rank=rank, world=world, transport=tr, device_id=local_rank, root=0,
                                             deep="auto" if args.dist_levels == 2 else False, payload=payload)
@@ -482,6 +486,23 @@ def main():
                     log(f"rank {rank}: transport {tr} is out: " + json.dumps([x for x in reports if not x["ok"]])[:2000])
                     if finished and box.get("drun") is not None:
                         box["drun"].close()
+            if not alive and last_resort is not None:
+                d = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0, rank=rank, world=world,
+                                    transport=last_resort, device_id=local_rank, root=0,
+                                    deep="auto" if args.dist_levels == 2 else False, payload=payload)
+                rep = d.selftest() if args.selftest == "on" else dict(ok=True, skipped=True)
+                rep.update(transport=last_resort, device=local_rank, probe_steps_per_s=None)
+                reports = [None] * world
+                dist.all_gather_object(reports, rep)
+                ok = all(x["ok"] for x in reports)
+                selftests.setdefault(name, []).append(dict(transport=last_resort, ok=ok, probe_steps_per_s=None, ranks=reports))
+                if ok:
+                    alive[last_resort] = d
+                    if len(candidates) > 1:  # (the others took the probe steps; this one starts the run itself)
+                        d.set_state(1.0, 0.0)
+                        d.ctx.set_poisson_options(**popt)
+                        d.ctx.begin_stage()
+                        d.ctx.run(PROBE_STEPS)
             if not alive:
                 raise RuntimeError("no transport passed its self-test: " + json.dumps(selftests[name])[:4000])
             rates = {t["transport"]: (t["probe_steps_per_s"] or 0.0) for t in selftests[name] if t["transport"] in alive}

@@ -41,6 +41,14 @@ def test_two_ranks_sharing_the_gpu_race_the_transports_and_report_it():
     assert "DRY RUN" in d["config"]["parallelism"] and "peer-mapped" in d["config"]["parallelism"]
 
 
+def test_when_no_device_transport_works_the_host_transport_still_yields_a_line():
+    d = _run("--gpus", "2", "--share-devices", "--workload", "60k", "--steps", "5", "--warmup", "2", "--preroll", "45",
+             "--no-cpu-baseline", "--config5", "off", "--debug-fail", "ipc,rccl")
+    tr = d["transport"]
+    assert tr["used"] == "gloo" and [t["ok"] for t in tr["selftest"]] == [False, False, True]
+    assert d["value"] > 0 and "host-callback" in d["config"]["parallelism"]
+
+
 def test_single_gpu_line_carries_the_contract_fields():
     d = _run("--workload", "60k", "--steps", "20", "--warmup", "5", "--preroll", "40", "--cpu-seconds", "2", "--vortex-window", "off")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
