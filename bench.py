@@ -605,10 +605,27 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+        # Decomposed runs: a physical check of the state the timed steps ended on, assembled from ALL ranks.  The step
+        # enforces div(J_s + J_n) = 0 at every site through the mu solve; on the sites next to a cut that sum runs over
+        # edges whose currents were formed from EXCHANGED psi and mu -- a stale or misplaced ghost value anywhere shows
+        # up as a divergence of the size of the currents, not of the solver's tolerance.
+        conservation = None
+        if use_dd:
+            fields = drun.gather_state()
+            if rank == 0:
+                em = wl.mesh.edge_mesh
+                flux = (fields["supercurrent"] + fields["normal_current"]) * em.dual_edge_lengths
+                div = (np.bincount(em.edges[:, 0], flux, minlength=n) - np.bincount(em.edges[:, 1], flux, minlength=n)) / wl.mesh.areas
+                jmax = float(max(np.abs(fields["supercurrent"]).max(), np.abs(fields["normal_current"]).max(), 1e-300))
+                part = drun.payload.get("part") if isinstance(drun.payload, dict) else None
+                conservation = dict(max_abs_divergence=float(np.abs(div).max()), max_abs_current=jmax,
+                                    relative=float(np.abs(div).max() / jmax), worst_site=int(np.abs(div).argmax()),
+                                    note="div(J_s + J_n) of the final state assembled from all ranks, against max |J|: of the "
+                                         "order of pcg_rtol if every exchanged value arrived where it belongs")
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), k1_burst_ms=k1_burst_ms, axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
-            end_state=end_state, work=work, setup=setup, windows={},
+            end_state=end_state, work=work, setup=setup, windows={}, conservation=conservation,
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats(), batch_prediction=ctx.pcg_prediction_stats()),
             overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
@@ -798,6 +815,7 @@ def main():
                                failures=[dict(rank=x.get("rank"), error=x.get("error"),
                                               bad=[c for c in x.get("checks", []) if not c["ok"]][:3])
                                          for x in t["ranks"] if not x["ok"]][:8]) for t in st])
+            d["conservation"] = r.conservation
             d["comm_per_step"] = dict(
                 halo_exchanges=round(r.comm["halos"] / args.steps, 1),
                 halo_bytes_sent=int(r.comm["halo_bytes"] / args.steps),
@@ -917,6 +935,7 @@ def main():
     if rank == 0 and "comm_per_step" in main_line:
         out["comm_per_step"] = main_line["comm_per_step"]
         out["transport"] = main_line.get("transport")
+        out["conservation"] = main_line.get("conservation")
     # BASELINE config 5 next to the headline workload (decomposed runs).  The headline measurement is
     # complete at this point: a watchdog thread prints it if the second workload does not finish in
     # time (a hung collective blocks inside the library, where no Python signal handler runs), so the

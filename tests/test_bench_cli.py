@@ -39,6 +39,8 @@ def test_two_ranks_sharing_the_gpu_race_the_transports_and_report_it():
     its = d["pcg"]["mean_iterations"]
     assert c["halo_exchanges"] <= 1.3 * its + 3.5 and c["deep_ghost_entries"] > c["ghost_sites"]
     assert "DRY RUN" in d["config"]["parallelism"] and "peer-mapped" in d["config"]["parallelism"]
+    # current conservation of the final state assembled from both ranks: solver tolerance, not O(1)
+    assert d["conservation"]["relative"] < 1e-7 and d["conservation"]["max_abs_current"] > 1e-3
 
 
 def test_when_no_device_transport_works_the_host_transport_still_yields_a_line():
