@@ -155,7 +155,7 @@ class TDGLContext:
     # meshes up to this many sites get the direct solve (one dense matrix-vector product per step,
     # `tdgl_poisson_set_dense_inverse`) unless build_poisson is told otherwise
     AMG_CANDIDATES = 3               # hierarchies built per iterative-regime mesh (the best one stays)
-    AMG_CANDIDATES_MIN_SITES = 200_000
+    AMG_CANDIDATES_MIN_SITES = 100_000
     DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "5000"))
     # ... and up to this many the substructured direct solve (`tdgl_poisson_set_substructure`): parts of
     # ~SUB_BLOCK sites with explicit inverses, a dense Schur complement on the separator
@@ -172,7 +172,7 @@ class TDGLContext:
         (default `DENSE_MAX_SITES`; 0 = never) additionally get the explicit pseudo-inverse of the
         Poisson matrix and solve with it (`set_dense_inverse`).
 
-        ``amg_candidates`` (default `AMG_CANDIDATES` from `AMG_CANDIDATES_MIN_SITES` sites on, else 1): the
+        ``amg_candidates`` (default `AMG_CANDIDATES` from `AMG_CANDIDATES_MIN_SITES` = 100k sites on when the solve is iterative, else 1): the
         aggregation's priorities are hashed, and the hierarchies different seeds give differ by luck -- 0.286 to 0.308
         in the PCG's convergence factor at 1M sites, 7.50 to 7.79 iterations per step in the time loop, the one
         predicting the other (profiles/EXPERIMENTS.md).  So this many are built, each solves ONE fixed pseudo-random
