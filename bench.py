@@ -173,6 +173,7 @@ def cpu_baseline(mesh, A, state, opt_kw, target_seconds=15.0, max_steps=40, term
 
 PARITY_TOL = 1e-8
 PARITY_STEPS = 20
+DD_PARITY_MAX_SITES = 1_200_000  # decomposed runs: the oracle's LU of the whole film has to fit the host and a minute
 
 
 def parity_block(hip_dt, hip_state, oracle_run, source):
@@ -567,11 +568,17 @@ def main():
             _junk = [np.empty(2_000_000, dtype=np.complex128) for _ in range(2)]
             for a in _junk:
                 a[:] = 1.0
-        if want_cpu_state:
-            st = ctx.get_state(supercurrent=False, normal_current=False)
+        # Decomposed runs at a size the oracle can follow: the state before and after the timed steps is assembled
+        # from all ranks (a collective: every rank takes part, rank 0 keeps the result) so that rank 0 can let the
+        # oracle take the same steps from the same state -- `parity_vs_oracle` of the decomposed path.
+        dd_parity = (use_dd and not args.no_parity and not args.no_cpu_baseline and args.steps <= PARITY_STEPS
+                     and n <= DD_PARITY_MAX_SITES)
+        if want_cpu_state or dd_parity:
+            st = drun.gather_state() if use_dd else ctx.get_state(supercurrent=False, normal_current=False)
             ls, cs = ctx.loop_state(), ctx.controller_state()
-            start_state = dict(psi=st["psi"], mu=st["mu"], step=ls["step"], time=ls["time"], dt=ls["dt"],
-                               tentative_dt=cs["tentative_dt"], history=cs["history"])
+            if rank == 0:
+                start_state = dict(psi=st["psi"], mu=st["mu"], step=ls["step"], time=ls["time"], dt=ls["dt"],
+                                   tentative_dt=cs["tentative_dt"], history=cs["history"])
             # Reading the state back (24 MB through pageable memory + NumPy) leaves the GPU idle for tens of
             # milliseconds, long enough for its clocks to drop: the 20 timed steps that follow then read 1.3-1.6 ms each
             # instead of 0.9 (three of three driver-flag runs of round 5 with the CPU baseline, none of three without).
@@ -612,6 +619,8 @@ def main():
         conservation = None
         if use_dd:
             fields = drun.gather_state()
+            if rank == 0 and dd_parity:
+                end_state = fields
             if rank == 0:
                 em = wl.mesh.edge_mesh
                 flux = (fields["supercurrent"] + fields["normal_current"]) * em.dual_edge_lengths
@@ -981,11 +990,14 @@ def main():
         K = min(args.steps, PARITY_STEPS) if want_parity else 0
         labels = [lb for lb in ("vortex", "late") if want_parity and r.windows.get(lb, {}).get("start") is not None]
         extra = [(r.windows[lb]["start"], K) for lb in labels]
-        base, oracle_run, extra_runs = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW, target_seconds=args.cpu_seconds,
+        # (decomposed runs: the oracle only follows the K timed steps -- `cpu_baseline` is a single-GPU figure)
+        base, oracle_run, extra_runs = cpu_baseline(wl.mesh, wl.A, r.start_state, OPT_KW,
+                                                    target_seconds=0.0 if use_dd else args.cpu_seconds, max_steps=K if use_dd else 40,
                                                     terms=wl.terms, currents=wl.currents, keep_at=K, extra_states=extra)
-        out["cpu_baseline"] = base
-        out["speedup_vs_cpu_baseline"] = round(out["value"] / base["value"], 1)
-        base["value"] = round(base["value"], 4)
+        if not use_dd:
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / base["value"], 1)
+            base["value"] = round(base["value"], 4)
 
         def hip_side(st0, timed_dt, end_state):
             """dt sequence and fields of the HIP path after K steps from the recorded state st0."""
@@ -1004,6 +1016,8 @@ def main():
 
         if want_parity:
             hip_dt, hip_state, source = hip_side(r.start_state, r.res["dt"], r.end_state)
+            if use_dd:
+                source += f", fields assembled from {world} rank(s) of the decomposed run"
             out["parity_vs_oracle"] = parity_block(hip_dt, hip_state, oracle_run, source)
             parity_failed = not out["parity_vs_oracle"]["ok"]
             log(f"parity vs oracle: {out['parity_vs_oracle']}")

@@ -43,6 +43,18 @@ def test_two_ranks_sharing_the_gpu_race_the_transports_and_report_it():
     assert d["conservation"]["relative"] < 1e-7 and d["conservation"]["max_abs_current"] > 1e-3
 
 
+def test_decomposed_run_is_followed_by_the_oracle_from_the_same_state():
+    """With the CPU leg on, a decomposed run's K timed steps are taken by the oracle too, from the state assembled from
+    both ranks before the clock started: `parity_vs_oracle` of the decomposed path (no `cpu_baseline`: that is a
+    single-GPU figure)."""
+    d = _run("--gpus", "2", "--share-devices", "--workload", "60k", "--steps", "10", "--warmup", "5", "--preroll", "45",
+             "--config5", "off")
+    par = d["parity_vs_oracle"]
+    assert par["ok"] and par["steps"] == 10 and "2 rank(s)" in par["source"], par
+    assert max(par[k] for k in ("dt", "abs_sq_psi", "mu_zero_mean", "J_s", "J_n")) <= par["tolerance"] == 1e-8
+    assert "cpu_baseline" not in d and d["transport"]["used"] == "ipc"
+
+
 def test_when_no_device_transport_works_the_host_transport_still_yields_a_line():
     d = _run("--gpus", "2", "--share-devices", "--workload", "60k", "--steps", "5", "--warmup", "2", "--preroll", "45",
              "--no-cpu-baseline", "--config5", "off", "--debug-fail", "ipc,rccl")
