@@ -266,6 +266,21 @@ typedef struct {
     const double *schur;      /* [n_sep, n_sep] row major                                       */
 } tdgl_substructure;
 int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, double *seconds);
+/* Second level of the nested dissection, for meshes whose first-level separator is too large for a dense
+ * matrix (~150k to ~350k sites).  Site order: part interiors, then the fine separators S'_Q of the Q
+ * super-blocks (the parts of a super-block lie inside it), then the top separator T, which covers every
+ * edge between two super-blocks (host layer: substructure.py: substructure_order2).  The first level is set
+ * with tdgl_poisson_set_substructure and `schur == NULL` (n_sep = |S'| + |T|; its `u` is not used); this call
+ * then describes the same construction on the first level's Schur complement S1 = A_SS - sum_p A_Sp E_p, a
+ * matrix on [S'_0 .. S'_{Q-1} | T] in which the S'_Q are decoupled from each other: n_interior = |S'|,
+ * n_sep = |T|, "parts" = the S'_Q, G_q = S1_qq^-1, E_q = G_q S1_qT, `schur` = S1_TT - sum_q S1_Tq E_q
+ * (singular; its pseudo-inverse is formed on the device), segments over the first level's separator vector.
+ * The gauge is carried down as a functional: the rows [n_interior + n_sep, + n_parts) are (G_q v_q)^T and
+ * u = v_T - sum_q E_q^T v_q with v = 1_S - sum_p E_p^T 1 of the first level, so that
+ * sum x = sum_p (G_p 1)^T b_p + sum_q (G_q v_q)^T r_q + u^T x_T.  A solve is six launches (down, down, the
+ * dense pair on T, up, up); the time loop, the run-ahead loop and the in-loop guard use it like the one-level
+ * form.  Until this call has succeeded the context keeps solving with AMG-PCG. */
+int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *inner, double *seconds);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
  * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep

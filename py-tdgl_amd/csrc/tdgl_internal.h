@@ -150,6 +150,14 @@ struct XrArgs {
     double *part_sx = nullptr;  // (optional) partials of sum x after the update: the zero-mean gauge needs no pass of its own
 };
 
+// a chunk of consecutive interior rows of ONE part of a substructure level, the work of one workgroup of the way up
+// (kernels.inc: k_sub_up): where the chunk's first row of E_p starts in the pool, where the part's separator index
+// list starts and how many entries it has (= the length of a row of E_p), the chunk's first row and its rows
+struct SubChunk {
+    int64_t e;
+    int32_t s0, cnt, row0, n_rows;
+};
+
 constexpr int GUESS_MAX = 16;  // maximal window of the projection guess (kernels.inc: GK)
 
 // Run-ahead time loop of the direct solves (run.inc: run_ahead): the adaptive-dt controller and the loop's
@@ -341,6 +349,24 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> sub_xs;          // [n_sep] separator solution before the mean is removed
     tdgl::DevBuf<double> sub_upart;       // per-workgroup partials of u . x_S
     int sub_nfin = 0;                     // workgroups of k_dense_sym_finish
+    // second level (tdgl_poisson_set_substructure_inner): the same construction on the first level's Schur
+    // complement -- its "parts" are the fine separators of the super-blocks, its separator the top separator T,
+    // whose pseudo-inverse is then the matrix in denseG (dense_n = |T|).  parts == 0: one level.
+    struct SubInner {
+        int32_t parts = 0;
+        int64_t nI = 0, nS = 0;           // fine-separator sites / |T|; nI + nS = sub_nS
+        tdgl::DevBuf<int32_t> part_ptr, seg_ptr, seg_x, seg_len, sep_ptr, sep_idx, row_part;
+        tdgl::DevBuf<int64_t> seg_val, e_off, g_off;
+        tdgl::DevBuf<double> vals, e, u;
+        tdgl::DevBuf<tdgl::SubChunk> chunks;
+        tdgl::DevBuf<double> w;           // [sub_nS + parts] way down of the second level
+        tdgl::DevBuf<double> xt;          // [|T|] top separator solution
+        int up_lanes = 16;
+    } sub2;
+    tdgl::DevBuf<tdgl::SubChunk> sub_chunks;
+    int sub_up_lanes = 16;                // lanes per row of E_p in k_sub_up (16, or 64 when the rows are long)
+    tdgl::DevBuf<double> sub_mean;        // [1] two levels: the mean of the solution, left by the second level's way up
+    bool sub_wait_inner = false;          // first level set without a Schur complement: not usable before the second is
     // run-ahead time loop (direct solves, static links): device-resident controller + per-step records
     tdgl::DevBuf<tdgl::StepCtl> d_ctl;
     tdgl::DevBuf<tdgl::StepRec> d_rec;

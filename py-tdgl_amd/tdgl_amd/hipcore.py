@@ -90,11 +90,22 @@ class TDGLContext:
         if n_owned:
             reorder = None
         self._sub_part_ptr = None
+        self._sub_super_ptr = None
         self.direct_solve = bool(direct_solve)
         if reorder == "rcm":
             with _Stopwatch(self.setup_times, "reorder"):
                 perm = rcm_permutation(em.edges, self.n)
-                if self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
+                if self.direct_solve and 0 < max(self.SUB_MAX_SITES, self.DENSE_MAX_SITES) < self.n <= self.SUB2_MAX_SITES \
+                        and self.SUB_MAX_SITES > 0:
+                    # ... and beyond, up to SUB2_MAX_SITES, two levels of it (part interiors, the fine separators
+                    # super-block by super-block, the top separator)
+                    from .substructure import substructure_order2
+
+                    rank = np.empty(self.n, dtype=np.int64)
+                    rank[perm] = np.arange(self.n)
+                    perm, self._sub_part_ptr, self._sub_super_ptr = substructure_order2(
+                        np.asarray(mesh.sites), em.edges, self.SUB2_BLOCK, self.SUB2_SUPER, rank_hint=rank)
+                elif self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
                     # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
                     # then the separator" as the site order (substructure.py); inside a part the sites keep
                     # their reverse Cuthill-McKee order
@@ -163,6 +174,13 @@ class TDGLContext:
     # (0 = by size: 192 sites per part up to 8k sites, 320 up to 60k, growing like n^(2/3) beyond -- the dense
     # Schur complement of the separator, ~2 n / sqrt(block) sites, is what grows fastest)
     SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "0"))
+    # two levels of it (`tdgl_poisson_set_substructure_inner`) up to here: parts of SUB2_BLOCK sites inside
+    # super-blocks of SUB2_SUPER sites (~0.9 GB per solve at 250k sites: G 177 MB, E 153, second level 192 + 146,
+    # top separator 224)
+    # (SUB_MAX_SITES = 0 switches both forms off)
+    SUB2_MAX_SITES = 350_000
+    SUB2_BLOCK = 128
+    SUB2_SUPER = 4096
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
@@ -252,7 +270,36 @@ class TDGLContext:
             A = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, self.iperm)
         sec = C.c_double(0.0)
         p_i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
-        if not os.environ.get("TDGL_SUB_HOST"):
+
+        def describe(pk):
+            return _lib.Substructure(
+                n_interior=pk["n_interior"], n_sep=pk["n_sep"], n_parts=pk["n_parts"], part_ptr=p_i32(pk["part_ptr"]),
+                seg_ptr=p_i32(pk["seg_ptr"]), seg_val=p_i64(pk["seg_val"]), seg_x=p_i32(pk["seg_x"]),
+                seg_len=p_i32(pk["seg_len"]), vals=p_f64(pk["vals"]), n_vals=len(pk["vals"]), sep_ptr=p_i32(pk["sep_ptr"]),
+                sep_idx=p_i32(pk["sep_idx"]), e_off=p_i64(pk["e_off"]), e_vals=p_f64(pk["e_vals"]),
+                n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=None if pk["schur"] is None else p_f64(pk["schur"]),
+            )
+
+        if self._sub_super_ptr is not None:
+            # two levels: the factors of both are formed on the host, the top separator's pseudo-inverse on the device
+            from .substructure import build_substructure2
+
+            with _Stopwatch(self.setup_times, "substructure_host"):
+                try:
+                    sub2 = build_substructure2(A, self._sub_part_ptr, self._sub_super_ptr)
+                except (ValueError, np.linalg.LinAlgError):
+                    return False
+                pk_o, pk_i = pack_for_device(sub2.outer), pack_for_device(sub2.inner)
+            status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(describe(pk_o)), C.byref(sec))
+            t_dev = sec.value
+            if status == _lib.TDGL_OK:
+                status = self._lib.tdgl_poisson_set_substructure_inner(self._ctx, C.byref(describe(pk_i)), C.byref(sec))
+                t_dev += sec.value
+            sec = C.c_double(t_dev)
+            info = dict(levels=2, parts=sub2.outer.n_parts, separator=sub2.outer.n_sep, super_blocks=sub2.inner.n_parts,
+                        top_separator=sub2.inner.n_sep, bytes_per_solve=sub2.bytes_per_solve(), built_on="host")
+            del sub2, pk_o, pk_i
+        elif not os.environ.get("TDGL_SUB_HOST"):
             # the factors are formed on the device; the host only describes the structure
             with _Stopwatch(self.setup_times, "substructure_host"):
                 try:
@@ -277,14 +324,7 @@ class TDGLContext:
                 except (ValueError, np.linalg.LinAlgError):
                     return False
                 pk = pack_for_device(sub)
-            d = _lib.Substructure(
-                n_interior=pk["n_interior"], n_sep=pk["n_sep"], n_parts=pk["n_parts"], part_ptr=p_i32(pk["part_ptr"]),
-                seg_ptr=p_i32(pk["seg_ptr"]), seg_val=p_i64(pk["seg_val"]), seg_x=p_i32(pk["seg_x"]),
-                seg_len=p_i32(pk["seg_len"]), vals=p_f64(pk["vals"]), n_vals=len(pk["vals"]), sep_ptr=p_i32(pk["sep_ptr"]),
-                sep_idx=p_i32(pk["sep_idx"]), e_off=p_i64(pk["e_off"]), e_vals=p_f64(pk["e_vals"]),
-                n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=p_f64(pk["schur"]),
-            )
-            status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(d), C.byref(sec))
+            status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(describe(pk)), C.byref(sec))
             info = dict(parts=sub.n_parts, separator=sub.n_sep, bytes_per_solve=sub.bytes_per_solve(), built_on="host")
         if status != _lib.TDGL_OK:
             return False

@@ -64,7 +64,7 @@ class Substructure:
     G: List[np.ndarray]           # per part [n_p, n_p]
     E: List[np.ndarray]           # per part [n_p, s_p]
     sep_idx: List[np.ndarray]     # per part: separator-local indices of the s_p separator sites it touches
-    schur: np.ndarray             # [n_S, n_S], symmetric, singular (null space: constants)
+    schur: np.ndarray             # [n_S, n_S], symmetric, singular (null space: constants); None: see `C`
     g: np.ndarray                 # [n_I]  G_p 1 per part, concatenated
     u: np.ndarray                 # [n_S]  -sum_p E_p^T 1
 
@@ -82,11 +82,18 @@ class Substructure:
 
     def bytes_per_solve(self):
         sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
-        return sum(8 * g.size for g in self.G) + 2 * sum(8 * e.size for e in self.E) + sym(self.n_sep)
+        return (sum(8 * g.size for g in self.G) + 2 * sum(8 * e.size for e in self.E)
+                + (sym(self.n_sep) if self.schur is not None else 0))
 
 
-def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray) -> Substructure:
-    """``A`` = the level-0 Poisson matrix in the internal order `substructure_order` produced."""
+def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray, weights: np.ndarray = None, with_schur: bool = True) -> Substructure:
+    """``A`` = the level-0 Poisson matrix in the internal order `substructure_order` produced.
+
+    ``weights`` (two-level form, `build_substructure2`): the functional whose value on the solution the factors
+    must deliver -- ``g = G_p w_p`` and ``u = w_S - sum_p E_p^T w_p`` so that ``w . x = g . b_I + u . x_S``
+    (default: ``w = 1`` with the ``1_S . x_S`` term dropped, x_S being the zero-sum solution of the Schur system).
+    ``with_schur=False``: the Schur complement is not formed densely (`Substructure.schur` is None); the blocks
+    ``A_Sp E_p`` are kept in `Substructure.C` instead."""
     A = A.tocsr()
     n = A.shape[0]
     P = len(part_ptr) - 1
@@ -94,11 +101,12 @@ def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray) -> Substructure:
     nS = n - nI
     if nS < 2:
         raise ValueError("substructure: no separator (a single part?)")
-    schur = A[nI:, nI:].toarray()
+    schur = A[nI:, nI:].toarray() if with_schur else None
     AIS = A[:nI, nI:].tocsr()
     AII = A[:nI, :nI].tocsr()
     g = np.empty(nI)
-    u = np.zeros(nS)
+    u = np.zeros(nS) if weights is None else np.array(weights[nI:], dtype=float)
+    w_int = np.ones(nI) if weights is None else np.asarray(weights[:nI], dtype=float)
 
     def one_part(p):
         a, b = int(part_ptr[p]), int(part_ptr[p + 1])
@@ -125,23 +133,149 @@ def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray) -> Substructure:
     with threadpool_limits(limits=1):
         with ThreadPoolExecutor(workers) as pool:
             results = list(pool.map(one_part, range(P)))
-    G, E, sidx = [], [], []
+    G, E, sidx, Cs = [], [], [], []
     for p, (Gp, Ep, cols, C) in enumerate(results):
         a, b = int(part_ptr[p]), int(part_ptr[p + 1])
-        schur[np.ix_(cols, cols)] -= C
+        if with_schur:
+            schur[np.ix_(cols, cols)] -= C
+        else:
+            Cs.append(C)
         G.append(Gp)
         E.append(Ep)
         sidx.append(cols)
-        g[a:b] = Gp.sum(axis=1)
-        u[cols] -= Ep.sum(axis=0)
+        g[a:b] = Gp @ w_int[a:b]
+        u[cols] -= Ep.T @ w_int[a:b]
     # interiors of different parts must not be coupled
     off = AII.tocoo()
     pr = np.searchsorted(part_ptr, off.row, side="right")
     pc = np.searchsorted(part_ptr, off.col, side="right")
     if np.any(pr != pc):
         raise ValueError("substructure: the separator does not cover every cut edge")
-    schur = 0.5 * (schur + schur.T)
-    return Substructure(n=n, part_ptr=np.asarray(part_ptr, dtype=np.int32), G=G, E=E, sep_idx=sidx, schur=schur, g=g, u=u)
+    if with_schur:
+        schur = 0.5 * (schur + schur.T)
+    out = Substructure(n=n, part_ptr=np.asarray(part_ptr, dtype=np.int32), G=G, E=E, sep_idx=sidx, schur=schur, g=g, u=u)
+    out.C = Cs
+    return out
+
+
+def substructure_order2(sites: np.ndarray, edges: np.ndarray, target_block: int = 128, target_super: int = 4096, rank_hint=None):
+    """Two levels of nested dissection.  The sites are cut into Q compact super-blocks (recursive coordinate
+    bisection) with a top separator T covering every edge between two of them; inside a super-block, T removed,
+    the sites are cut into parts of ~``target_block`` sites with a fine separator S'_Q covering the edges between
+    two parts.  Internal order: part interiors (part by part, the parts of a super-block together), then S'_0,
+    S'_1, ... , then T.  Returns ``perm`` (internal -> reference site), ``part_ptr`` ([P + 1] interior ranges)
+    and ``super_ptr`` ([Q + 1]: the range of S'_Q is ``[super_ptr[Q], super_ptr[Q + 1])``, T is
+    ``[super_ptr[Q], n)``).  Seen from the first level the separator is everything behind ``part_ptr[-1]``; seen
+    from the second, the S'_Q are the "parts" of the first level's Schur complement (decoupled from each other:
+    every path between two super-blocks passes T) and T is its separator."""
+    sites = np.asarray(sites, dtype=float)
+    n = len(sites)
+    nsuper = max(2, int(round(n / float(target_super))))
+    sup = rcb_partition(sites, nsuper)
+    i, j = edges[:, 0], edges[:, 1]
+    is_T = np.zeros(n, dtype=bool)
+    is_T[i[sup[i] < sup[j]]] = True
+    is_T[j[sup[j] < sup[i]]] = True
+    part = np.full(n, -1, dtype=np.int64)
+    nparts = 0
+    for q in range(nsuper):
+        idx = np.flatnonzero((sup == q) & ~is_T)
+        if len(idx) == 0:
+            continue
+        k = max(1, int(round(len(idx) / float(target_block))))
+        part[idx] = nparts + (rcb_partition(sites[idx], k) if k > 1 else 0)
+        nparts += k
+    free = ~is_T[i] & ~is_T[j]
+    is_S = np.zeros(n, dtype=bool)
+    is_S[i[free & (part[i] < part[j])]] = True
+    is_S[j[free & (part[j] < part[i])]] = True
+    key = np.arange(n) if rank_hint is None else np.asarray(rank_hint)
+    group = np.where(is_T, nparts + nsuper, np.where(is_S, nparts + sup, part))
+    perm = np.lexsort((key, group)).astype(np.int32)
+    counts = np.bincount(group, minlength=nparts + nsuper + 1)
+    part_ptr = np.concatenate([[0], np.cumsum(counts[:nparts])]).astype(np.int32)
+    super_ptr = (part_ptr[-1] + np.concatenate([[0], np.cumsum(counts[nparts:nparts + nsuper])])).astype(np.int32)
+    return perm, part_ptr, super_ptr
+
+
+@dataclass
+class Substructure2:
+    """Two-level factors: `outer` eliminates the part interiors (no dense Schur complement), `inner` is the
+    same construction applied to the outer level's Schur complement S1 on [S'_0 .. S'_{Q-1} | T]."""
+    outer: Substructure
+    inner: Substructure
+
+    def bytes_per_solve(self):
+        return self.outer.bytes_per_solve() + self.inner.bytes_per_solve()
+
+
+def build_substructure2(A: sp.spmatrix, part_ptr: np.ndarray, super_ptr: np.ndarray) -> Substructure2:
+    """``A`` in the internal order of `substructure_order2`."""
+    A = A.tocsr()
+    n = A.shape[0]
+    nI = int(part_ptr[-1])
+    nS = n - nI
+    outer = build_substructure(A, part_ptr, with_schur=False)
+    # S1 = A_SS - sum_p A_Sp E_p as a sparse matrix: the blocks of different super-blocks do not overlap
+    # outside T, so it has ~ (|S'_Q| + |T_Q|)^2 entries per super-block
+    rows, cols, vals = [], [], []
+    for idx, C in zip(outer.sep_idx, outer.C):
+        k = len(idx)
+        rows.append(np.repeat(idx, k))
+        cols.append(np.tile(idx, k))
+        vals.append(-C.ravel())
+    ASS = A[nI:, nI:].tocoo()
+    rows.append(ASS.row)
+    cols.append(ASS.col)
+    vals.append(ASS.data)
+    S1 = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nS, nS)).tocsr()
+    S1 = (0.5 * (S1 + S1.T)).tocsr()
+    outer.C = None
+    # the functional sum x = sum_p g_p . b_p + v . x_S with v = 1_S - sum_p E_p^T 1 is carried down a level
+    v = 1.0 + outer.u
+    inner = build_substructure(S1, np.asarray(super_ptr, dtype=np.int64) - nI, weights=v)
+    return Substructure2(outer=outer, inner=inner)
+
+
+def solve_host2(sub2: Substructure2, b: np.ndarray, spinv: np.ndarray = None, remove_mean: bool = True) -> np.ndarray:
+    """The two-level device sequence in NumPy (six launches: down, down, dense pair, up, up)."""
+    o, q = sub2.outer, sub2.inner
+    nI, P = o.n_interior, o.n_parts
+    if remove_mean:
+        b = b - b.mean()
+    y = np.empty(nI)
+    r = b[nI:].copy()
+    total = 0.0
+    for p in range(P):
+        a, e = int(o.part_ptr[p]), int(o.part_ptr[p + 1])
+        y[a:e] = o.G[p] @ b[a:e]
+        r[o.sep_idx[p]] -= o.E[p].T @ b[a:e]
+        total += o.g[a:e] @ b[a:e]
+    # the Schur system S1 x_S = r on the second level; no gauge: v . x_S is what the first level needs
+    nI2, Q = q.n_interior, q.n_parts
+    if spinv is None:
+        spinv = schur_pinv(q.schur)
+    y2 = np.empty(nI2)
+    rT = r[nI2:].copy()
+    for k in range(Q):
+        a, e = int(q.part_ptr[k]), int(q.part_ptr[k + 1])
+        y2[a:e] = q.G[k] @ r[a:e]
+        rT[q.sep_idx[k]] -= q.E[k].T @ r[a:e]
+        total += q.g[a:e] @ r[a:e]
+    xT = spinv @ rT
+    total += q.u @ xT
+    xs = np.empty(o.n_sep)
+    for k in range(Q):
+        a, e = int(q.part_ptr[k]), int(q.part_ptr[k + 1])
+        xs[a:e] = y2[a:e] - q.E[k] @ xT[q.sep_idx[k]]
+    xs[nI2:] = xT
+    mean = total / o.n
+    x = np.empty(o.n)
+    for p in range(P):
+        a, e = int(o.part_ptr[p]), int(o.part_ptr[p + 1])
+        x[a:e] = y[a:e] - o.E[p] @ xs[o.sep_idx[p]] - mean
+    x[nI:] = xs - mean
+    return x
 
 
 def schur_pinv(schur: np.ndarray) -> np.ndarray:
@@ -241,7 +375,8 @@ def pack_for_device(sub: Substructure):
         n_interior=nI, n_sep=nS, n_parts=P, part_ptr=pp.astype(np.int32),
         seg_ptr=seg_ptr, seg_val=seg_val.astype(np.int64), seg_x=seg_x.astype(np.int32), seg_len=seg_len.astype(np.int32),
         vals=np.ascontiguousarray(vals), sep_ptr=sep_ptr, sep_idx=sep_idx, e_off=e_off[:-1].copy(),
-        e_vals=np.ascontiguousarray(e_vals), u=np.ascontiguousarray(sub.u), schur=np.ascontiguousarray(sub.schur),
+        e_vals=np.ascontiguousarray(e_vals), u=np.ascontiguousarray(sub.u),
+        schur=None if sub.schur is None else np.ascontiguousarray(sub.schur),
     )
 
 

@@ -37,6 +37,7 @@ def golden():
 
 _PRODUCT_DENSE_MAX_SITES = None
 _PRODUCT_SUB_MAX_SITES = None
+_PRODUCT_SUB2_MAX_SITES = None
 
 
 @pytest.fixture(autouse=True, scope="session")
@@ -46,16 +47,18 @@ def _iterative_mu_solve_unless_asked():
     the suites keep the AMG-PCG path under test by default (session-wide, so that module-scoped contexts
     see it too); tests that request the ``direct_solve`` fixture (tests/test_hip_direct.py re-runs the
     trajectory suite that way) get the product default back."""
-    global _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES
+    global _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES, _PRODUCT_SUB2_MAX_SITES
     try:
         from tdgl_amd.hipcore import TDGLContext
     except Exception:  # (library not built: the tests that need it fail on their own)
         yield
         return
     _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES = TDGLContext.DENSE_MAX_SITES, TDGLContext.SUB_MAX_SITES
-    TDGLContext.DENSE_MAX_SITES = TDGLContext.SUB_MAX_SITES = 0
+    _PRODUCT_SUB2_MAX_SITES = TDGLContext.SUB2_MAX_SITES
+    TDGLContext.DENSE_MAX_SITES = TDGLContext.SUB_MAX_SITES = TDGLContext.SUB2_MAX_SITES = 0
     yield
     TDGLContext.DENSE_MAX_SITES, TDGLContext.SUB_MAX_SITES = _PRODUCT_DENSE_MAX_SITES, _PRODUCT_SUB_MAX_SITES
+    TDGLContext.SUB2_MAX_SITES = _PRODUCT_SUB2_MAX_SITES
 
 
 @pytest.fixture
@@ -65,6 +68,8 @@ def direct_solve(monkeypatch):
     assert _PRODUCT_DENSE_MAX_SITES >= 4000 and _PRODUCT_SUB_MAX_SITES >= 60000  # the product defaults cover the reference's documented mesh sizes
     monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", _PRODUCT_DENSE_MAX_SITES)
     monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", _PRODUCT_SUB_MAX_SITES)
+    monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", _PRODUCT_SUB2_MAX_SITES)
+    assert _PRODUCT_SUB2_MAX_SITES >= 250_000  # ... and BASELINE config 2
     return _PRODUCT_DENSE_MAX_SITES
 
 
@@ -78,3 +83,17 @@ def substructured_solve(monkeypatch):
     monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", 10 ** 9)
     monkeypatch.setattr(TDGLContext, "SUB_BLOCK", 150)
     return 150
+
+
+@pytest.fixture
+def two_level_solve(monkeypatch):
+    """Every mesh from 200 sites up takes the TWO-level substructured direct mu solve (parts of ~60 sites inside
+    super-blocks of ~500), which the product uses between `SUB_MAX_SITES` and `SUB2_MAX_SITES`."""
+    from tdgl_amd.hipcore import TDGLContext
+
+    monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", 199)
+    monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", 199)
+    monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", 10 ** 9)
+    monkeypatch.setattr(TDGLContext, "SUB2_BLOCK", 60)
+    monkeypatch.setattr(TDGLContext, "SUB2_SUPER", 500)
+    return 60

@@ -1079,6 +1079,56 @@ def test_substructured_solve_on_the_host():
     assert np.abs(w - np.concatenate([y, r, gd])).max() < 1e-12 * np.abs(w).max()
 
 
+def test_two_level_substructured_solve_on_the_host():
+    """Two levels of nested dissection (substructure_order2 / build_substructure2): the order -- part interiors, the
+    fine separators super-block by super-block, the top separator -- decouples what it must, the second level is the
+    first level's construction applied to its Schur complement, and the six-launch sequence (solve_host2) returns
+    pinv(A) b with the gauge carried down as a functional."""
+    from tdgl_amd.amg import exact_pinv
+    from tdgl_amd.hipcore import poisson_matrix, rcm_permutation
+    from tdgl_amd.substructure import build_substructure2, pack_for_device, down_host, solve_host2, substructure_order2
+
+    mesh = synthetic_mesh(40)
+    em = mesh.edge_mesh
+    n = len(mesh.sites)
+    rcm = rcm_permutation(em.edges, n)
+    rank = np.empty(n, dtype=np.int64)
+    rank[rcm] = np.arange(n)
+    perm, pp, sp_ = substructure_order2(mesh.sites, em.edges, 60, 500, rank_hint=rank)
+    assert sorted(perm.tolist()) == list(range(n)) and pp[0] == 0 and sp_[0] == pp[-1] and sp_[-1] < n
+    P, Q = len(pp) - 1, len(sp_) - 1
+    assert Q >= 3 and P >= 4 * Q
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[perm] = np.arange(n)
+    A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, n, iperm)
+    # fine separators of different super-blocks are not coupled, neither directly ...
+    blk = np.searchsorted(sp_, np.arange(sp_[0], sp_[-1]), side="right")
+    C = A[sp_[0]:sp_[-1], sp_[0]:sp_[-1]].tocoo()
+    assert np.all(blk[C.row] == blk[C.col])
+    sub2 = build_substructure2(A, pp, sp_)  # ... nor through a part (the second level's build raises otherwise)
+    o, q = sub2.outer, sub2.inner
+    assert o.schur is None and o.n_interior + o.n_sep == n and q.n_interior + q.n_sep == o.n_sep and q.n_parts == Q
+    assert np.abs(q.schur.sum(axis=1)).max() < 1e-11 * np.abs(q.schur).max()  # singular like A
+    b = np.random.default_rng(3).standard_normal(n)
+    b -= b.mean()
+    x = solve_host2(sub2, b)
+    want = exact_pinv(A) @ b
+    assert np.abs(x - want).max() < 1e-11 * np.abs(want).max() and abs(x.mean()) < 1e-14
+    assert np.abs(solve_host2(sub2, b + 1e-3) - want).max() < 1e-11 * np.abs(want).max()
+    # the packed form of the second level works on the first level's separator vector
+    pk = pack_for_device(q)
+    r = np.random.default_rng(4).standard_normal(o.n_sep)
+    w = down_host(pk, r)
+    qp = q.part_ptr
+    y = np.concatenate([q.G[k] @ r[qp[k]:qp[k + 1]] for k in range(Q)])
+    rT = r[q.n_interior:].copy()
+    for k in range(Q):
+        rT[q.sep_idx[k]] -= q.E[k].T @ r[qp[k]:qp[k + 1]]
+    gd = np.array([q.g[qp[k]:qp[k + 1]] @ r[qp[k]:qp[k + 1]] for k in range(Q)])
+    assert np.abs(w - np.concatenate([y, rT, gd])).max() < 1e-12 * np.abs(w).max()
+    assert pack_for_device(o)["schur"] is None
+
+
 # ---------------------------------------------------------------- native mesh set-up (include/tdgl_host_mesh.h)
 def _triangle_set(tri):
     tri = np.sort(np.asarray(tri), axis=1)
