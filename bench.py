@@ -305,6 +305,7 @@ def main():
                     help="run the coarse AMG levels kernel by kernel instead of through the collapsed operators")
     ap.add_argument("--tail-cycles", type=int, default=2,
                     help="V-cycles folded into the explicit operators of the tail level (1 = the plain cycle)")
+    ap.add_argument("--sub-limits", default="", help=argparse.SUPPRESS)  # "SUB_MAX,SUB2_MAX,SUB2_BLOCK,SUB2_SUPER" (tuning runs)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip `parity_vs_oracle` (it needs the CPU baseline leg: the oracle's steps are the reference side)")
@@ -388,6 +389,12 @@ def main():
 
     from tdgl_amd import SolverOptions, TDGLSolver
 
+    if args.sub_limits:
+        from tdgl_amd.hipcore import TDGLContext
+
+        for name, v in zip(("SUB_MAX_SITES", "SUB2_MAX_SITES", "SUB2_BLOCK", "SUB2_SUPER"), args.sub_limits.split(",")):
+            if v:
+                setattr(TDGLContext, name, int(v))
     opts = SolverOptions(**OPT_KW, pcg_rtol=args.rtol, edge_currents_every_step=True, device_id=local_rank)
     popt = dict(rtol=args.rtol, max_iter=opts.pcg_max_iter, nu=args.nu, check_every=args.check_every,
                 edge_currents_every_step=True, smoother=args.smoother, extrapolate=args.extrapolate,

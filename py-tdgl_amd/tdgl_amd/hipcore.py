@@ -103,8 +103,10 @@ class TDGLContext:
 
                     rank = np.empty(self.n, dtype=np.int64)
                     rank[perm] = np.arange(self.n)
+                    block2 = self.SUB2_BLOCK or (128 if self.n < 200_000 else 160)
+                    super2 = self.SUB2_SUPER or max(2048, self.n // 60)
                     perm, self._sub_part_ptr, self._sub_super_ptr = substructure_order2(
-                        np.asarray(mesh.sites), em.edges, self.SUB2_BLOCK, self.SUB2_SUPER, rank_hint=rank)
+                        np.asarray(mesh.sites), em.edges, block2, super2, rank_hint=rank)
                 elif self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
                     # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
                     # then the separator" as the site order (substructure.py); inside a part the sites keep
@@ -170,17 +172,21 @@ class TDGLContext:
     DENSE_MAX_SITES = int(__import__("os").environ.get("TDGL_DENSE_MAX_SITES", "5000"))
     # ... and up to this many the substructured direct solve (`tdgl_poisson_set_substructure`): parts of
     # ~SUB_BLOCK sites with explicit inverses, a dense Schur complement on the separator
-    SUB_MAX_SITES = int(__import__("os").environ.get("TDGL_SUB_MAX_SITES", "150000"))
+    SUB_MAX_SITES = int(__import__("os").environ.get("TDGL_SUB_MAX_SITES", "32000"))
     # (0 = by size: 192 sites per part up to 8k sites, 320 up to 60k, growing like n^(2/3) beyond -- the dense
     # Schur complement of the separator, ~2 n / sqrt(block) sites, is what grows fastest)
     SUB_BLOCK = int(__import__("os").environ.get("TDGL_SUB_BLOCK", "0"))
-    # two levels of it (`tdgl_poisson_set_substructure_inner`) up to here: parts of SUB2_BLOCK sites inside
-    # super-blocks of SUB2_SUPER sites (~0.9 GB per solve at 250k sites: G 177 MB, E 153, second level 192 + 146,
-    # top separator 224)
+    # two levels of it (`tdgl_poisson_set_substructure_inner`) from there up to SUB2_MAX_SITES: parts of SUB2_BLOCK
+    # sites inside super-blocks of SUB2_SUPER sites (0 = by size: 128 / 160 sites per part below / above 200k sites,
+    # super-blocks of n / 60 sites but at least 2,048 -- the dense matrix of the top separator grows like n^2 /
+    # SUB2_SUPER, the dense fine separators like n * SUB2_SUPER / SUB2_BLOCK).  Measured, steps/s with one level /
+    # two levels: 23k sites 21.4k / 17.9k, 59k sites 9.4k / 14.2k, 120k sites 4.2k / 7.4k, 250k sites AMG-PCG 2.4k /
+    # 3.9k (0.9 GB per solve there: G 232 MB, E 176, second level 234 + 164, top separator 224); the strip of 500k
+    # sites stays iterative (1.8k against 3.8k steps/s in its stationary state, where the guess is exact).
     # (SUB_MAX_SITES = 0 switches both forms off)
     SUB2_MAX_SITES = 350_000
-    SUB2_BLOCK = 128
-    SUB2_SUPER = 4096
+    SUB2_BLOCK = 0
+    SUB2_SUPER = 0
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",

@@ -65,7 +65,8 @@ def _iterative_mu_solve_unless_asked():
 def direct_solve(monkeypatch):
     from tdgl_amd.hipcore import TDGLContext
 
-    assert _PRODUCT_DENSE_MAX_SITES >= 4000 and _PRODUCT_SUB_MAX_SITES >= 60000  # the product defaults cover the reference's documented mesh sizes
+    # the product defaults cover the reference's documented mesh sizes with a direct solve (one level, then two)
+    assert _PRODUCT_DENSE_MAX_SITES >= 4000 and _PRODUCT_SUB_MAX_SITES >= 16000 and _PRODUCT_SUB2_MAX_SITES >= 60000
     monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", _PRODUCT_DENSE_MAX_SITES)
     monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", _PRODUCT_SUB_MAX_SITES)
     monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", _PRODUCT_SUB2_MAX_SITES)
