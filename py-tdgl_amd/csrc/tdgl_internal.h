@@ -158,6 +158,19 @@ struct SubChunk {
     int32_t s0, cnt, row0, n_rows;
 };
 
+// the way down (kernels.inc: k_sub_down): a chunk of consecutive interior rows of ONE part -- where its first row of
+// G_p starts in the pool, where b_p starts, the part's size, the chunk's first row and its rows -- and a row of the
+// rest (separator rows, (G_p 1)^T rows) with up to four segments inline (nseg < 0: more, see the segment lists)
+struct SubDownChunk {
+    int64_t g;
+    int32_t x0, ncols, row0, n_rows;
+};
+struct SubDownRow {
+    int32_t nseg, pad;
+    int64_t val[4];
+    int32_t x[4], len[4];
+};
+
 constexpr int GUESS_MAX = 16;  // maximal window of the projection guess (kernels.inc: GK)
 
 // Run-ahead time loop of the direct solves (run.inc: run_ahead): the adaptive-dt controller and the loop's
@@ -359,11 +372,15 @@ struct tdgl_ctx {
         tdgl::DevBuf<int64_t> seg_val, e_off, g_off;
         tdgl::DevBuf<double> vals, e, u;
         tdgl::DevBuf<tdgl::SubChunk> chunks;
+        tdgl::DevBuf<tdgl::SubDownChunk> down_chunks;
+        tdgl::DevBuf<tdgl::SubDownRow> down_rows;
         tdgl::DevBuf<double> w;           // [sub_nS + parts] way down of the second level
         tdgl::DevBuf<double> xt;          // [|T|] top separator solution
         int up_lanes = 16;
     } sub2;
     tdgl::DevBuf<tdgl::SubChunk> sub_chunks;
+    tdgl::DevBuf<tdgl::SubDownChunk> sub_down_chunks;
+    tdgl::DevBuf<tdgl::SubDownRow> sub_down_rows;
     int sub_up_lanes = 16;                // lanes per row of E_p in k_sub_up (16, or 64 when the rows are long)
     tdgl::DevBuf<double> sub_mean;        // [1] two levels: the mean of the solution, left by the second level's way up
     bool sub_wait_inner = false;          // first level set without a Schur complement: not usable before the second is
