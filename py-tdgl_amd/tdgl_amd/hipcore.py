@@ -293,9 +293,12 @@ class TDGLContext:
             with _Stopwatch(self.setup_times, "substructure_host"):
                 try:
                     sub2 = build_substructure2(A, self._sub_part_ptr, self._sub_super_ptr)
-                except (ValueError, np.linalg.LinAlgError):
+                    pk_o, pk_i = pack_for_device(sub2.outer), pack_for_device(sub2.inner)
+                except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
+                    # (a mesh the dissection cannot cut as it expects -- a super-block without interior, pieces that are
+                    # not connected: the iterative solve takes it)
+                    self.setup_times["substructure_error"] = repr(exc)
                     return False
-                pk_o, pk_i = pack_for_device(sub2.outer), pack_for_device(sub2.inner)
             status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(describe(pk_o)), C.byref(sec))
             t_dev = sec.value
             if status == _lib.TDGL_OK:

@@ -1,3 +1,6 @@
+#!/bin/bash
+# Direct-solve session on a GPU box: the direct-solve tests, bench lines at the sizes the direct mu solves cover, and a kernel
+# trace of the 250k-site workload.  bash tools/gpu_direct.sh TAG
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 TAG=$1
