@@ -150,12 +150,13 @@ struct XrArgs {
     double *part_sx = nullptr;  // (optional) partials of sum x after the update: the zero-mean gauge needs no pass of its own
 };
 
-// a chunk of consecutive interior rows of ONE part of a substructure level, the work of one workgroup of the way up
-// (kernels.inc: k_sub_up): where the chunk's first row of E_p starts in the pool, where the part's separator index
-// list starts and how many entries it has (= the length of a row of E_p), the chunk's first row and its rows
-struct SubChunk {
-    int64_t e;
-    int32_t s0, cnt, row0, n_rows;
+// up to 64 consecutive interior rows of ONE part of a substructure level, the work of one wavefront of the way up
+// (kernels.inc: k_sub_up): where column `first row` of the part's -E_p^T block starts in the value pool, the part's
+// size (= the block's row length), where the part's separator index list starts and how many entries it has,
+// the chunk's first row and its rows
+struct SubUpChunk {
+    int64_t et;
+    int32_t np, s0, cnt, row0, n_rows;
 };
 
 // the way down (kernels.inc: k_sub_down): a chunk of consecutive interior rows of ONE part -- where its first row of
@@ -371,17 +372,15 @@ struct tdgl_ctx {
         tdgl::DevBuf<int32_t> part_ptr, seg_ptr, seg_x, seg_len, sep_ptr, sep_idx, row_part;
         tdgl::DevBuf<int64_t> seg_val, e_off, g_off;
         tdgl::DevBuf<double> vals, e, u;
-        tdgl::DevBuf<tdgl::SubChunk> chunks;
+        tdgl::DevBuf<tdgl::SubUpChunk> chunks;
         tdgl::DevBuf<tdgl::SubDownChunk> down_chunks;
         tdgl::DevBuf<tdgl::SubDownRow> down_rows;
         tdgl::DevBuf<double> w;           // [sub_nS + parts] way down of the second level
         tdgl::DevBuf<double> xt;          // [|T|] top separator solution
-        int up_lanes = 16;
     } sub2;
-    tdgl::DevBuf<tdgl::SubChunk> sub_chunks;
+    tdgl::DevBuf<tdgl::SubUpChunk> sub_chunks;
     tdgl::DevBuf<tdgl::SubDownChunk> sub_down_chunks;
     tdgl::DevBuf<tdgl::SubDownRow> sub_down_rows;
-    int sub_up_lanes = 16;                // lanes per row of E_p in k_sub_up (16, or 64 when the rows are long)
     tdgl::DevBuf<double> sub_mean;        // [1] two levels: the mean of the solution, left by the second level's way up
     bool sub_wait_inner = false;          // first level set without a Schur complement: not usable before the second is
     // run-ahead time loop (direct solves, static links): device-resident controller + per-step records
