@@ -115,26 +115,39 @@ def test_config4_strip_500k_current_conservation_and_poisson_residual():
     _values_match_the_oracle(mesh, uniform_field_A(mesh, 0.0), ctx, st, float(res["dt"][-1]), fixed=fixed, mu_boundary=mu_b)
 
 
-def test_config2_250k_uniform_field_first_steps_match_oracle():
-    """BASELINE config 2 (250,510 sites, b = 0.1): 12 steps against the oracle (SuperLU)."""
+_ORACLE_250K = {}
+
+
+@pytest.mark.parametrize("mu_solver", ["amg_pcg", "product_default"])
+def test_config2_250k_uniform_field_first_steps_match_oracle(mu_solver, request):
+    """BASELINE config 2 (250,510 sites, b = 0.1): 12 steps against the oracle (SuperLU), with the iterative mu solve
+    and with the product default at this size (the two-level direct solve: ~1,500 parts in 61 super-blocks)."""
     from types import SimpleNamespace
 
     from oracle import OracleSolver, run_time_loop
     from tdgl_amd import SolverOptions, TDGLSolver
 
+    if mu_solver == "product_default":
+        request.getfixturevalue("direct_solve")
     mesh = synthetic_mesh(465)
     assert len(mesh.sites) == 250510
     A = uniform_field_A(mesh, 0.1)
     kw = dict(solve_time=1e9, dt_init=1e-3, save_every=10**6)
     solver = TDGLSolver.from_dimensionless(mesh, SolverOptions(**kw, pcg_rtol=1e-11), A, 1.0, U_DEFAULT, GAMMA_DEFAULT)
     ctx = solver.ctx
+    sub = ctx.substructure
+    assert (sub is not None and sub["levels"] == 2 and sub["super_blocks"] > 40) == (mu_solver == "product_default")
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     res = ctx.run(12)
     got = ctx.get_state()
-    o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
-                        adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)
-    want = run_time_loop(OracleSolver(mesh, A, 1.0, U_DEFAULT, GAMMA_DEFAULT, o), o, max_steps=12)
+    assert (res["pcg_iters"].max() == 0) == (mu_solver == "product_default")
+    ctx.close()
+    if "want" not in _ORACLE_250K:
+        o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
+                            adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)
+        _ORACLE_250K["want"] = run_time_loop(OracleSolver(mesh, A, 1.0, U_DEFAULT, GAMMA_DEFAULT, o), o, max_steps=12)
+    want = _ORACLE_250K["want"]
     assert max_abs(res["dt"], want["log"].array("dt")) < 1e-9 * res["dt"].max()
     assert max_abs(np.abs(got["psi"]) ** 2, np.abs(want["psi"]) ** 2) < 1e-9
     assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-9
