@@ -29,8 +29,12 @@ for L in [int(a) for a in sys.argv[1:]] or [100, 200]:
     ctx.begin_stage()
     ms = ctx.time_kernel(7, reps=5)
     pairs = float(n) * m
-    print(json.dumps(dict(L=L, sites=n, edges=m, kernel_ms=ms, pairs_per_s=pairs / (ms * 1e-3),
-                          tflops_fp64=12 * pairs / (ms * 1e-3) / 1e12)), flush=True)
+    tf = 12 * pairs / (ms * 1e-3) / 1e12
+    # (the kernel is bound by the fp64 VECTOR rate, 78.6 TFLOP/s on MI355X: a reciprocal square root per pair, not a contraction)
+    roofline = dict(bound="fp64 vector", kernel="k_induced_vector_potential", achieved=round(tf, 2), peak=78.6, unit="TFLOP/s",
+                    frac=round(tf / 78.6, 4), flops_per_pair=12, pairs=pairs, avg_launch_ms=ms)
+    print(json.dumps(dict(L=L, sites=n, edges=m, kernel_ms=ms, pairs_per_s=pairs / (ms * 1e-3), tflops_fp64=tf,
+                          roofline_screening=roofline)), flush=True)
     t0 = time.perf_counter()
     try:
         res = ctx.run(20)
