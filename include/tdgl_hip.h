@@ -281,6 +281,15 @@ int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, dou
  * dense pair on T, up, up); the time loop, the run-ahead loop and the in-loop guard use it like the one-level
  * form.  Until this call has succeeded the context keeps solving with AMG-PCG. */
 int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *inner, double *seconds);
+/* Optional, per level (0: the first, 1: the second): the sparse coupling block of the level's matrix, separator rows x
+ * interior columns (A_SI as CSR [n_sep, n_interior]; for the second level S1_TS').  The level's separator right-hand
+ * side is then formed as r_S = b_S - A_SI y_I by a sparse product BEHIND the dense one (y_I = G b_I must be complete:
+ * a launch of its own) and the separator rows of the level's description must hold their identity segment only --
+ * the -E_p^T rows are not streamed on the way down any more (a fifth of a two-level solve's bytes at 250k sites, for
+ * two more launches: pays from ~150k sites on).  A level described that way is not used (the context keeps solving with
+ * AMG-PCG) until its coupling block has arrived.  Call after the level's factors are set. */
+int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const int32_t *indptr, const int32_t *indices,
+                                           const double *data);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
  * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep

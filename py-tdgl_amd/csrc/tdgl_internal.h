@@ -377,11 +377,16 @@ struct tdgl_ctx {
         tdgl::DevBuf<tdgl::SubDownRow> down_rows;
         tdgl::DevBuf<double> w;           // [sub_nS + parts] way down of the second level
         tdgl::DevBuf<double> xt;          // [|T|] top separator solution
+        tdgl::Csr coupling;               // (optional) S1_TS' [|T| x nI]: r_T = r_T - coupling y_q, see sub_coupling
     } sub2;
     tdgl::DevBuf<tdgl::SubUpChunk> sub_chunks;
     tdgl::DevBuf<tdgl::SubDownChunk> sub_down_chunks;
     tdgl::DevBuf<tdgl::SubDownRow> sub_down_rows;
     tdgl::DevBuf<double> sub_mean;        // [1] two levels: the mean of the solution, left by the second level's way up
+    // (optional, tdgl_poisson_set_substructure_coupling) A_SI [sub_nS x sub_nI]: the separator right-hand side of the way
+    // down as r_S = b_S - A_SI y_I, a sparse product behind the dense one, instead of the -E_p^T rows inside it
+    tdgl::Csr sub_coupling;
+    bool sub_need_coupling[2] = {false, false};  // a level was described without its -E^T rows and its coupling block is not there yet
     bool sub_wait_inner = false;          // first level set without a Schur complement: not usable before the second is
     // run-ahead time loop (direct solves, static links): device-resident controller + per-step records
     tdgl::DevBuf<tdgl::StepCtl> d_ctl;

@@ -185,6 +185,9 @@ class TDGLContext:
     # sites stays iterative (1.8k against 3.8k steps/s in its stationary state, where the guess is exact).
     # (SUB_MAX_SITES = 0 switches both forms off)
     SUB2_MAX_SITES = 350_000
+    # from here on the separator right-hand sides of the way down come from the sparse coupling blocks (two more
+    # launches, no -E^T rows: `tdgl_poisson_set_substructure_coupling`)
+    SUB2_SPARSE_SEP_MIN_SITES = 150_000
     SUB2_BLOCK = 0
     SUB2_SUPER = 0
 
@@ -293,7 +296,8 @@ class TDGLContext:
             with _Stopwatch(self.setup_times, "substructure_host"):
                 try:
                     sub2 = build_substructure2(A, self._sub_part_ptr, self._sub_super_ptr)
-                    pk_o, pk_i = pack_for_device(sub2.outer), pack_for_device(sub2.inner)
+                    sparse_sep = self.n >= self.SUB2_SPARSE_SEP_MIN_SITES
+                    pk_o, pk_i = pack_for_device(sub2.outer, sparse_sep), pack_for_device(sub2.inner, sparse_sep)
                 except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
                     # (a mesh the dissection cannot cut as it expects -- a super-block without interior, pieces that are
                     # not connected: the iterative solve takes it)
@@ -304,9 +308,19 @@ class TDGLContext:
             if status == _lib.TDGL_OK:
                 status = self._lib.tdgl_poisson_set_substructure_inner(self._ctx, C.byref(describe(pk_i)), C.byref(sec))
                 t_dev += sec.value
+            if status == _lib.TDGL_OK and sparse_sep:
+                for level, M in ((0, sub2.outer.coupling), (1, sub2.inner.coupling)):
+                    keep_c = (i32(M.indptr), i32(M.indices), f64(M.data))
+                    status = self._lib.tdgl_poisson_set_substructure_coupling(self._ctx, level, p_i32(keep_c[0]), p_i32(keep_c[1]),
+                                                                              p_f64(keep_c[2]))
+                    if status != _lib.TDGL_OK:
+                        break
             sec = C.c_double(t_dev)
-            info = dict(levels=2, parts=sub2.outer.n_parts, separator=sub2.outer.n_sep, super_blocks=sub2.inner.n_parts,
-                        top_separator=sub2.inner.n_sep, bytes_per_solve=sub2.bytes_per_solve(), built_on="host")
+            info = dict(levels=2, sparse_separator_rhs=bool(sparse_sep), parts=sub2.outer.n_parts, separator=sub2.outer.n_sep, super_blocks=sub2.inner.n_parts,
+                        top_separator=sub2.inner.n_sep, built_on="host",
+                        bytes_per_solve=sub2.bytes_per_solve() - (0 if not sparse_sep else sum(
+                            8 * e.size for lv in (sub2.outer, sub2.inner) for e in lv.E) - 12 * (
+                                sub2.outer.coupling.nnz + sub2.inner.coupling.nnz)))
             del sub2, pk_o, pk_i
         elif not os.environ.get("TDGL_SUB_HOST"):
             # the factors are formed on the device; the host only describes the structure

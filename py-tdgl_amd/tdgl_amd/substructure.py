@@ -234,11 +234,17 @@ def build_substructure2(A: sp.spmatrix, part_ptr: np.ndarray, super_ptr: np.ndar
     # the functional sum x = sum_p g_p . b_p + v . x_S with v = 1_S - sum_p E_p^T 1 is carried down a level
     v = 1.0 + outer.u
     inner = build_substructure(S1, np.asarray(super_ptr, dtype=np.int64) - nI, weights=v)
+    # the sparse coupling blocks (separator rows x interior columns) of both levels: r_S = b_S - A_SI y_I
+    outer.coupling = A[nI:, :nI].tocsr()
+    nI2 = int(super_ptr[-1]) - nI
+    inner.coupling = S1[nI2:, :nI2].tocsr()
     return Substructure2(outer=outer, inner=inner)
 
 
-def solve_host2(sub2: Substructure2, b: np.ndarray, spinv: np.ndarray = None, remove_mean: bool = True) -> np.ndarray:
-    """The two-level device sequence in NumPy (six launches: down, down, dense pair, up, up)."""
+def solve_host2(sub2: Substructure2, b: np.ndarray, spinv: np.ndarray = None, remove_mean: bool = True,
+                sparse_sep: bool = False) -> np.ndarray:
+    """The two-level device sequence in NumPy (six launches: down, down, dense pair, up, up; ``sparse_sep``: the
+    separator right-hand sides through the sparse coupling blocks, two more launches, a fifth of the bytes less)."""
     o, q = sub2.outer, sub2.inner
     nI, P = o.n_interior, o.n_parts
     if remove_mean:
@@ -249,8 +255,11 @@ def solve_host2(sub2: Substructure2, b: np.ndarray, spinv: np.ndarray = None, re
     for p in range(P):
         a, e = int(o.part_ptr[p]), int(o.part_ptr[p + 1])
         y[a:e] = o.G[p] @ b[a:e]
-        r[o.sep_idx[p]] -= o.E[p].T @ b[a:e]
+        if not sparse_sep:
+            r[o.sep_idx[p]] -= o.E[p].T @ b[a:e]
         total += o.g[a:e] @ b[a:e]
+    if sparse_sep:
+        r -= o.coupling @ y
     # the Schur system S1 x_S = r on the second level; no gauge: v . x_S is what the first level needs
     nI2, Q = q.n_interior, q.n_parts
     if spinv is None:
@@ -260,8 +269,11 @@ def solve_host2(sub2: Substructure2, b: np.ndarray, spinv: np.ndarray = None, re
     for k in range(Q):
         a, e = int(q.part_ptr[k]), int(q.part_ptr[k + 1])
         y2[a:e] = q.G[k] @ r[a:e]
-        rT[q.sep_idx[k]] -= q.E[k].T @ r[a:e]
+        if not sparse_sep:
+            rT[q.sep_idx[k]] -= q.E[k].T @ r[a:e]
         total += q.g[a:e] @ r[a:e]
+    if sparse_sep:
+        rT -= q.coupling @ y2
     xT = spinv @ rT
     total += q.u @ xT
     xs = np.empty(o.n_sep)
@@ -319,8 +331,12 @@ def solve_host(sub: Substructure, b: np.ndarray, spinv: np.ndarray = None, remov
     return x
 
 
-def pack_for_device(sub: Substructure):
-    """Flat arrays of `tdgl_substructure` (include/tdgl_hip.h): the way down as rows of dense segments
+def pack_for_device(sub: Substructure, sparse_sep: bool = False):
+    """``sparse_sep``: the separator rows of the way down keep their identity segment only -- the library forms
+    ``r_S = b_S - A_SI y_I`` with the sparse coupling block instead (`tdgl_poisson_set_substructure_coupling`), which
+    needs ``y_I`` complete, i.e. a launch of its own, but not the -E^T rows (a fifth of a two-level solve's bytes).
+
+    Flat arrays of `tdgl_substructure` (include/tdgl_hip.h): the way down as rows of dense segments
     over one value pool -- rows [0, n_I): ``G_p`` rows; rows [n_I, n): ``b_S`` itself (a segment of one
     entry with value 1) minus the ``E_p^T`` rows of the parts that touch the site; rows [n, n + P):
     ``(G_p 1)^T`` -- and the way up as the ``E_p`` blocks with their separator index lists."""
@@ -352,7 +368,7 @@ def pack_for_device(sub: Substructure):
     seg_x.append(nI + np.arange(nS, dtype=np.int64))
     seg_len.append(np.ones(nS, dtype=np.int64))
     seg_row.append(nI + np.arange(nS, dtype=np.int64))
-    for p in range(P):
+    for p in range(0 if sparse_sep else P):
         k = len(sub.sep_idx[p])
         seg_val.append(et_off[p] + np.arange(k, dtype=np.int64) * sizes[p])
         seg_x.append(np.full(k, pp[p], dtype=np.int64))
