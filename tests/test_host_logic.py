@@ -1127,6 +1127,14 @@ def test_two_level_substructured_solve_on_the_host():
     gd = np.array([q.g[qp[k]:qp[k + 1]] @ r[qp[k]:qp[k + 1]] for k in range(Q)])
     assert np.abs(w - np.concatenate([y, rT, gd])).max() < 1e-12 * np.abs(w).max()
     assert pack_for_device(o)["schur"] is None
+    # the sparse form of the separator right-hand sides: r_S = b_S - A_SI y_I, no -E^T rows on the way down
+    assert np.abs(solve_host2(sub2, b, sparse_sep=True) - want).max() < 1e-11 * np.abs(want).max()
+    assert o.coupling.shape == (o.n_sep, o.n_interior) and q.coupling.shape == (q.n_sep, q.n_interior)
+    pks = pack_for_device(q, sparse_sep=True)
+    assert np.all(np.diff(pks["seg_ptr"])[q.n_interior:q.n_interior + q.n_sep] == 1)  # the identity segment alone
+    ws = down_host(pks, r)
+    assert np.abs(ws[:q.n_interior] - y).max() < 1e-12 * np.abs(y).max()
+    assert np.abs((ws[q.n_interior:q.n_interior + q.n_sep] - q.coupling @ ws[:q.n_interior]) - rT).max() < 1e-11 * np.abs(rT).max()
 
 
 # ---------------------------------------------------------------- native mesh set-up (include/tdgl_host_mesh.h)
