@@ -58,6 +58,8 @@ WORKLOADS = {
     "23k": (140.0, "square film 140 xi, ~23k sites"),
     "120k": (320.0, "square film 320 xi, ~120k sites"),
     "160k": (370.0, "square film 370 xi, ~160k sites"),
+    "350k": (550.0, "square film 550 xi, ~350k sites"),
+    "450k": (622.0, "square film 622 xi, ~450k sites"),
     "60k": (226.0, "square film 226 xi, 59,377 sites"),
     "250k": (465.0, "square film 465 xi, 250,510 sites"),
     "1M": (930.0, "square film 930 xi, 1,000,431 sites"),
@@ -392,7 +394,8 @@ def main():
     if args.sub_limits:
         from tdgl_amd.hipcore import TDGLContext
 
-        for name, v in zip(("SUB_MAX_SITES", "SUB2_MAX_SITES", "SUB2_BLOCK", "SUB2_SUPER"), args.sub_limits.split(",")):
+        for name, v in zip(("SUB_MAX_SITES", "SUB2_MAX_SITES", "SUB2_BLOCK", "SUB2_SUPER", "SUB2_SPARSE_SEP_MIN_SITES"),
+                           args.sub_limits.split(",")):
             if v:
                 setattr(TDGLContext, name, int(v))
     opts = SolverOptions(**OPT_KW, pcg_rtol=args.rtol, edge_currents_every_step=True, device_id=local_rank)

@@ -267,7 +267,7 @@ typedef struct {
 } tdgl_substructure;
 int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, double *seconds);
 /* Second level of the nested dissection, for meshes whose first-level separator is too large for a dense
- * matrix (~150k to ~350k sites).  Site order: part interiors, then the fine separators S'_Q of the Q
+ * matrix (~32k to ~480k sites).  Site order: part interiors, then the fine separators S'_Q of the Q
  * super-blocks (the parts of a super-block lie inside it), then the top separator T, which covers every
  * edge between two super-blocks (host layer: substructure.py: substructure_order2).  The first level is set
  * with tdgl_poisson_set_substructure and `schur == NULL` (n_sep = |S'| + |T|; its `u` is not used); this call
@@ -286,7 +286,7 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
  * side is then formed as r_S = b_S - A_SI y_I by a sparse product BEHIND the dense one (y_I = G b_I must be complete:
  * a launch of its own) and the separator rows of the level's description must hold their identity segment only --
  * the -E_p^T rows are not streamed on the way down any more (a fifth of a two-level solve's bytes at 250k sites, for
- * two more launches: pays from ~150k sites on).  A level described that way is not used (the context keeps solving with
+ * two more launches: pays from ~200k sites on).  A level described that way is not used (the context keeps solving with
  * AMG-PCG) until its coupling block has arrived.  Call after the level's factors are set. */
 int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const int32_t *indptr, const int32_t *indices,
                                            const double *data);

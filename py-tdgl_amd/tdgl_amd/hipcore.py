@@ -184,10 +184,14 @@ class TDGLContext:
     # 3.9k (0.9 GB per solve there: G 232 MB, E 176, second level 234 + 164, top separator 224); the strip of 500k
     # sites stays iterative (1.8k against 3.8k steps/s in its stationary state, where the guess is exact).
     # (SUB_MAX_SITES = 0 switches both forms off)
-    SUB2_MAX_SITES = 350_000
+    # Upper limit: the direct solve costs the same whatever the state, AMG-PCG as much as mu is unpredictable -- 350k
+    # sites 3.0k against 2.0k steps/s, 450k 2.3k against 1.9k in an evolving vortex state; the 500k-site strip with terminals
+    # in its STATIONARY state (an exact guess, 1.5 iterations) 1.8k against 3.8k; estimated crossover for evolving states ~550k.
+    SUB2_MAX_SITES = 480_000
     # from here on the separator right-hand sides of the way down come from the sparse coupling blocks (two more
     # launches, no -E^T rows: `tdgl_poisson_set_substructure_coupling`)
-    SUB2_SPARSE_SEP_MIN_SITES = 150_000
+    # (measured: 60k sites 13.0k against 13.6k steps/s, 120k 7.5k / 8.1k, 160k 5.9k / 6.2k, 250k 4.1k / 3.9k)
+    SUB2_SPARSE_SEP_MIN_SITES = 200_000
     SUB2_BLOCK = 0
     SUB2_SUPER = 0
 
