@@ -145,6 +145,9 @@ def _segment_distance(pts, a, b, within=None):
     return out
 
 
+MIN_BOUNDARY_ANGLE_DEG = 1.0  # interior (or exterior) angle between consecutive boundary segments, see _polygon_mesh_at_pitch
+
+
 def polygon_mesh(film, holes=(), max_edge_length=1.0, seed=0, max_rounds=12, backend="native"):
     """Boundary-conforming Delaunay mesh of ``film`` minus ``holes`` (closed or open ``(k, 2)``
     vertex arrays) with no edge longer than ``max_edge_length``.  Returns ``(points, triangles)``.
@@ -157,6 +160,12 @@ def polygon_mesh(film, holes=(), max_edge_length=1.0, seed=0, max_rounds=12, bac
         if longest <= max_edge_length:
             return pts, tri
         pitch *= 0.97 * max_edge_length / longest
+        if pitch < 0.65 * float(max_edge_length) / 3.0:
+            # (a few per cent of adjustment is normal; an edge many times too long means the boundary could not be
+            # resolved -- a needle-shaped notch or spike narrower than the pitch -- and a lattice fine enough to hide
+            # it would have 10x the points asked for)
+            raise RuntimeError(f"polygon_mesh: an edge of length {longest:.3g} remains at max_edge_length = {max_edge_length:g} "
+                               "(a notch or spike of the boundary much narrower than that?)")
     raise RuntimeError("polygon_mesh: could not satisfy max_edge_length")  # pragma: no cover
 
 
@@ -172,14 +181,42 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds, backend="native"):
         keep = np.linalg.norm(poly - np.roll(poly, 1, axis=0), axis=1) > 1e-12 * max(1.0, np.abs(poly).max())
         loops.append(poly[keep])
 
+    # Two boundary segments that meet at a very small angle encroach on each other however often they are split
+    # (Ruppert's small-angle problem; the concentric-shell remedy is not implemented): say so instead of refining
+    # until the memory is gone.
+    for lp in loops:
+        if len(lp) < 3:
+            raise ValueError("polygon_mesh: a boundary loop needs at least three distinct vertices")
+        a = np.roll(lp, 1, axis=0) - lp
+        b = np.roll(lp, -1, axis=0) - lp
+        cosang = (a * b).sum(axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        k = int(np.argmax(cosang))
+        ang = float(np.degrees(np.arccos(np.clip(cosang[k], -1.0, 1.0))))
+        if ang < MIN_BOUNDARY_ANGLE_DEG:
+            raise ValueError(f"polygon_mesh: the boundary turns by all but {ang:.2f} degrees at vertex {k} "
+                             f"({lp[k][0]:.6g}, {lp[k][1]:.6g}); corners sharper than {MIN_BOUNDARY_ANGLE_DEG:g} degrees "
+                             "cannot be meshed with well-shaped cells -- round or cut the spike")
+
     def resample(loop):
-        pts = []
-        for p0, p1 in zip(loop, np.roll(loop, -1, axis=0)):
+        # (also: which of the points are input vertices where the boundary turns by more than 120 degrees -- the two
+        # segments there encroach on each other's diametral circles unless they are cut at equal distances from the
+        # vertex, see the split below)
+        a = np.roll(loop, 1, axis=0) - loop
+        b = np.roll(loop, -1, axis=0) - loop
+        cosang = (a * b).sum(axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        sharp = cosang > 0.5  # interior or exterior angle below 60 degrees
+        pts, flags = [], []
+        for j, (p0, p1) in enumerate(zip(loop, np.roll(loop, -1, axis=0))):
             k = max(1, int(np.ceil(np.linalg.norm(p1 - p0) / h)))
             pts.append(p0 + (p1 - p0) * (np.arange(k) / k)[:, None])
-        return np.concatenate(pts)
+            f = np.zeros(k, dtype=bool)
+            f[0] = sharp[j]
+            flags.append(f)
+        return np.concatenate(pts), np.concatenate(flags)
 
-    bloops = [resample(lp) for lp in loops]
+    resampled = [resample(lp) for lp in loops]
+    bloops = [r[0] for r in resampled]
+    bsharp = [r[1] for r in resampled]
     (x0, y0), (x1, y1) = loops[0].min(axis=0), loops[0].max(axis=0)
     lattice = hex_jitter_points(x1 - x0 + 2 * h, y1 - y0 + 2 * h, pitch=h, seed=seed,
                                 center=(0.5 * (x0 + x1), 0.5 * (y0 + y1)))
@@ -199,14 +236,20 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds, backend="native"):
         inside = _points_in_poly(loops[0], cent)
         for hole in loops[1:]:
             inside &= ~_points_in_poly(hole, cent)
+        # Points resampled along an OBLIQUE straight side are collinear only up to rounding: the triangulation of their
+        # convex hull then contains slivers of ~1e-15 height along that side whose centroids pass for inside.  They are
+        # not cells of the mesh (their edges skip boundary points); drop them.
+        pa, pb, pc = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+        area2 = np.abs((pb[:, 0] - pa[:, 0]) * (pc[:, 1] - pa[:, 1]) - (pb[:, 1] - pa[:, 1]) * (pc[:, 0] - pa[:, 0]))
+        inside &= area2 > 1e-9 * h * h
         tri = tri[inside]
         edges = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
         edge_keys = np.unique(edges[:, 0] * np.int64(len(pts)) + edges[:, 1])
         tree = cKDTree(pts)
         split = False
         off = 0
-        new_loops = []
-        for b, n_b in zip(bloops, nb):
+        new_loops, new_sharp = [], []
+        for b, n_b, shp in zip(bloops, nb, bsharp):
             idx = off + np.arange(n_b)
             nxt = off + (np.arange(n_b) + 1) % n_b
             mids = 0.5 * (pts[idx] + pts[nxt])
@@ -217,20 +260,34 @@ def _polygon_mesh_at_pitch(film, holes, h, seed, max_rounds, backend="native"):
             present = (pos < len(edge_keys)) & (edge_keys[np.minimum(pos, len(edge_keys) - 1)] == keys)
             # (ii) no other point strictly inside its diametral circle: the tree proposes, the distance decides
             near = tree.query_ball_point(mids, rad)
-            out = []
+            out, out_sharp = [], []
             for k in range(n_b):
                 cand = np.asarray([j for j in near[k] if j != idx[k] and j != nxt[k]], dtype=np.int64)
                 encroached = bool(len(cand)) and bool(
                     (np.linalg.norm(pts[cand] - mids[k], axis=1) < rad[k] * (1 - 1e-12)).any())
                 out.append(b[k])
+                out_sharp.append(bool(shp[k]))
                 if not present[k] or encroached:
-                    out.append(mids[k])
+                    k2 = (k + 1) % n_b
+                    cut = mids[k]
+                    if shp[k] != shp[k2]:
+                        # one end is a sharp input vertex: cut on a concentric shell around it (a power of two times
+                        # the pitch, the one nearest to the midpoint), so that the two segments that meet there end
+                        # up with pieces of EQUAL length next to the vertex and stop encroaching on each other
+                        v, w = (b[k], b[k2]) if shp[k] else (b[k2], b[k])
+                        length = 2.0 * rad[k]
+                        d = h * 2.0 ** np.round(np.log2(0.5 * length / h))
+                        if 0.2 * length < d < 0.8 * length:
+                            cut = v + (w - v) * (d / length)
+                    out.append(cut)
+                    out_sharp.append(False)
                     split = True
             new_loops.append(np.array(out))
+            new_sharp.append(np.array(out_sharp, dtype=bool))
             off += n_b
         if not split:
             break
-        bloops = new_loops
+        bloops, bsharp = new_loops, new_sharp
         # lattice points too close to a refined boundary piece are dropped
         ba = np.concatenate(bloops)
         bb = np.concatenate([np.roll(b, -1, axis=0) for b in bloops])

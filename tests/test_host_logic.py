@@ -233,6 +233,41 @@ def test_polygon_mesher_with_holes_is_boundary_conforming():
     assert not Polygon("c", points=circle(1.4, center=(-2.5, 0))).contains_points(mesh.sites).any()
 
 
+def test_polygon_mesher_on_oblique_sides_and_sharp_corners():
+    """Sides that are not axis-parallel and corners far below 60 degrees (round 5: such shapes never came back from the
+    mesher).  Points resampled along an oblique side are collinear only up to rounding, so the hull's triangulation has
+    zero-height slivers along it, whose edges skip boundary points -- dropped; and the two sides of a sharp corner
+    encroach on each other's diametral circles for ever unless they are cut at equal distances from the corner
+    (concentric shells).  Checked: the mesh comes back quickly, covers the polygon's area exactly, respects
+    max_edge_length, has positive cells; a needle below one degree is refused with a message."""
+    import time
+
+    from tdgl_amd.finite_volume import Mesh
+    from tdgl_amd.meshgen import polygon_mesh
+
+    for deg in (45.0, 20.0, 8.0, 1.5):
+        t = np.radians(deg)
+        film = np.array([[0.0, 0.0], [20.0, 0.0], [20.0 * np.cos(t), 20.0 * np.sin(t)]])
+        t0 = time.perf_counter()
+        pts, tri = polygon_mesh(film, [], max_edge_length=0.7)
+        assert time.perf_counter() - t0 < 20.0
+        mesh = Mesh.from_triangulation(pts, tri)
+        assert np.isclose(mesh.areas.sum(), 0.5 * 20.0 * 20.0 * np.sin(t), rtol=1e-12) and mesh.areas.min() > 0
+        assert mesh.edge_mesh.edge_lengths.max() <= 0.7 and mesh.edge_mesh.dual_edge_lengths.min() >= -1e-12
+    # a star-shaped film with a 10-degree notch and a hole (a random polygon that used to eat the host's memory)
+    film = np.array([[21.454, 6.273], [12.547, 3.969], [16.570, 5.840], [-6.565, 28.691], [-20.626, 18.563], [-22.299, 14.453],
+                     [-16.556, -1.599], [6.711, -17.611], [22.887, -0.118]])
+    th = np.linspace(0.0, 2.0 * np.pi, 24, endpoint=False)
+    hole = np.c_[2.0 + 1.5 * np.cos(th), 1.0 + 1.5 * np.sin(th)]
+    pts, tri = polygon_mesh(film, [hole], max_edge_length=0.6)
+    mesh = Mesh.from_triangulation(pts, tri)
+    shoelace = lambda p: 0.5 * abs(np.dot(p[:, 0], np.roll(p[:, 1], -1)) - np.dot(p[:, 1], np.roll(p[:, 0], -1)))
+    assert np.isclose(mesh.areas.sum(), shoelace(film) - shoelace(hole), rtol=1e-11) and mesh.areas.min() > 0
+    assert 8000 < len(pts) < 20000 and mesh.edge_mesh.edge_lengths.max() <= 0.6
+    with pytest.raises(ValueError, match="sharper than"):
+        polygon_mesh(np.array([[0.0, 0.0], [20.0, 0.0], [20.0, 0.1]]), [], max_edge_length=0.7)
+
+
 def test_make_mesh_with_smoothing_keeps_boundary_and_topology():
     from tdgl_amd import Device, Layer, Polygon
     from tdgl_amd.geometry import box, circle
