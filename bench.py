@@ -66,13 +66,14 @@ WORKLOADS = {
     "4M": (1860.0, "square film 1860 xi, 3,998,502 sites"),
     # BASELINE config 4: strip with two current terminals (short edges), I = 0.2 * Ly, zero field
     "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly"),
+    "strip250k": ((920.0, 236.0), "strip 920 x 236 xi, ~251k sites, two current terminals, I = 0.2 Ly"),
     # the same strip just above the depairing current density (2 / (3 sqrt 3) = 0.385 in these units)
     "strip500k_ps": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.39 Ly (just above the depairing current)"),
     # ... and in a perpendicular field with the sub-critical current: vortices enter at the long edges and are driven across (flux flow)
     "strip500k_ff": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly, uniform field b = 0.02 (flux flow)"),
 }
-STRIP_CURRENT = {"strip500k": 0.2, "strip500k_ps": 0.39, "strip500k_ff": 0.2}
-STRIP_FIELD = {"strip500k": 0.0, "strip500k_ps": 0.0, "strip500k_ff": 0.02}
+STRIP_CURRENT = {"strip250k": 0.2, "strip500k": 0.2, "strip500k_ps": 0.39, "strip500k_ff": 0.2}
+STRIP_FIELD = {"strip250k": 0.0, "strip500k": 0.0, "strip500k_ps": 0.0, "strip500k_ff": 0.02}
 B_FIELD = 0.1  # B / Bc2
 
 
@@ -649,7 +650,8 @@ def main():
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
             k1=(launches, k1_ms), k1_burst_ms=k1_burst_ms, axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
             end_state=end_state, work=work, setup=setup, windows={}, conservation=conservation,
-            stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats(), batch_prediction=ctx.pcg_prediction_stats()),
+            stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats(), batch_prediction=ctx.pcg_prediction_stats(),
+                       **(dict(direct_switching=ctx.direct_switching()) if getattr(ctx, "dense_direct", False) else {})),
             overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
@@ -718,6 +720,7 @@ def main():
             retries=int(work["psi_retries"]), host_syncs_per_step=round(work["host_syncs"] / max(work["steps"], 1), 2),
             dt=dict(mean=float(res["dt"].mean()), min=float(res["dt"].min()), max=float(res["dt"].max())),
             guess=ctx.guess_stats(),
+            **(dict(direct_switching=ctx.direct_switching()) if getattr(ctx, "dense_direct", False) else {}),
         )
 
     def late_window(r):

@@ -288,6 +288,16 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
  * the -E_p^T rows are not streamed on the way down any more (a fifth of a two-level solve's bytes at 250k sites, for
  * two more launches: pays from ~200k sites on).  A level described that way is not used (the context keeps solving with
  * AMG-PCG) until its coupling block has arrived.  Call after the level's factors are set. */
+/* Solver choice in the time loop, for contexts that hold BOTH a direct mu solve and the AMG hierarchy.  A direct
+ * solve costs the same whatever the state; AMG-PCG from the projection guess costs next to nothing once the state is
+ * stationary (a transport current through a strip: 0 iterations) and more than the direct solve while vortices move
+ * (251k-site strip, stationary: 7.1k against 4.3k steps/s; 250k-site film in a field: 2.4k against 4.3k).  on = 1: while
+ * |psi|^2 has changed by less than 2e-5 per step for 64 accepted steps the direct solve is paused (one
+ * synchronisation per step, AMG-PCG); when the running mean of the PCG iterations exceeds 2.5 it comes back, and
+ * the next pause has to wait twice as long (256 steps at first).  on = 0: off (the direct solve always); on < 0: query
+ * only.  *switches / *paused (may be NULL): changes so far, the current state.  The host layer switches it on from
+ * 150k sites. */
+int tdgl_direct_switching(tdgl_ctx *ctx, int32_t on, int64_t *switches, int32_t *paused);
 int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const int32_t *indptr, const int32_t *indices,
                                            const double *data);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller

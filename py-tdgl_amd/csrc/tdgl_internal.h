@@ -387,6 +387,20 @@ struct tdgl_ctx {
     // down as r_S = b_S - A_SI y_I, a sparse product behind the dense one, instead of the -E_p^T rows inside it
     tdgl::Csr sub_coupling;
     bool sub_need_coupling[2] = {false, false};  // a level was described without its -E^T rows and its coupling block is not there yet
+    // Solver choice in the time loop (tdgl_direct_switching; meshes where BOTH a direct solve and the hierarchy are
+    // resident and large enough for the choice to matter).  A direct solve costs the same whatever the state; AMG-PCG
+    // started from the projection guess costs next to nothing once the state is stationary (a transport current
+    // through a strip: 0 iterations) and more than the direct solve while vortices move.  So: direct by default; while
+    // |psi|^2 has changed by less than DIRECT_PAUSE_DMAX per step for DIRECT_PAUSE_WINDOW steps the direct solve is
+    // paused (dense_on() is false: classic loop, AMG-PCG); when the iterations' running mean exceeds
+    // DIRECT_RESUME_ITERS it comes back, and the next pause has to wait twice as long.
+    bool direct_switch_on = false, direct_paused = false;
+    int64_t direct_switch_steps = 0;       // accepted steps since the last switch
+    int64_t direct_pause_hold = 256;       // steps the direct solve runs at least before it may be paused again
+    int64_t direct_switches = 0;
+    double direct_recent_dmax[64] = {0};   // ring of the last accepted steps' max d|psi|^2
+    int64_t direct_recent_n = 0;
+    double direct_pcg_ema = 0.0;
     bool sub_wait_inner = false;          // first level set without a Schur complement: not usable before the second is
     // run-ahead time loop (direct solves, static links): device-resident controller + per-step records
     tdgl::DevBuf<tdgl::StepCtl> d_ctl;

@@ -234,6 +234,7 @@ SIGNATURES = {
     "tdgl_poisson_build_dense_inverse": (C.c_int, [_CTX, c_f64p]),
     "tdgl_poisson_set_substructure": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
     "tdgl_poisson_set_substructure_inner": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
+    "tdgl_direct_switching": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tdgl_poisson_set_substructure_coupling": (C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p]),
     "tdgl_poisson_build_substructure": (C.c_int, [_CTX, C.POINTER(SubstructurePlan), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),

@@ -192,6 +192,10 @@ class TDGLContext:
     # launches, no -E^T rows: `tdgl_poisson_set_substructure_coupling`)
     # (measured: 60k sites 13.0k against 13.6k steps/s, 120k 7.5k / 8.1k, 160k 5.9k / 6.2k, 250k 4.1k / 3.9k)
     SUB2_SPARSE_SEP_MIN_SITES = 200_000
+    # from here on the time loop may pause the direct solve in stationary states (`tdgl_direct_switching`): a 251k-site
+    # strip with a transport current runs 7.1k steps/s on AMG-PCG (0 iterations) against 4.3k on the direct solve; below
+    # ~150k sites the iterative step is launch-bound and the direct solve wins in every state
+    DIRECT_SWITCH_MIN_SITES = 150_000
     SUB2_BLOCK = 0
     SUB2_SUPER = 0
 
@@ -361,7 +365,18 @@ class TDGLContext:
             return False
         self.substructure = info
         self.dense_direct = True
+        # large enough for the iterative solve to beat the direct one in a stationary state: let the loop choose
+        if self.n >= self.DIRECT_SWITCH_MIN_SITES:
+            self.direct_switching(True)
         return True
+
+    def direct_switching(self, on=None):
+        """`tdgl_direct_switching`: let the time loop pause the direct mu solve while the state is stationary (AMG-PCG
+        from the projection guess is then the cheaper solve) -- ``on`` True / False sets it, None only queries.
+        Returns ``dict(switches, paused)``."""
+        sw, pa = C.c_int64(0), C.c_int32(0)
+        self._chk(self._lib.tdgl_direct_switching(self._ctx, -1 if on is None else int(bool(on)), C.byref(sw), C.byref(pa)))
+        return dict(switches=int(sw.value), paused=bool(pa.value))
 
     def build_dense_inverse(self, A=None, check_rtol=1e-11) -> bool:
         """Switch the mu solve to the explicit pseudo-inverse (`tdgl_poisson_set_dense_inverse`): built on
