@@ -60,6 +60,7 @@ WORKLOADS = {
     "160k": (370.0, "square film 370 xi, ~160k sites"),
     "350k": (550.0, "square film 550 xi, ~350k sites"),
     "450k": (622.0, "square film 622 xi, ~450k sites"),
+    "600k": (720.0, "square film 720 xi, ~600k sites"),
     "60k": (226.0, "square film 226 xi, 59,377 sites"),
     "250k": (465.0, "square film 465 xi, 250,510 sites"),
     "1M": (930.0, "square film 930 xi, 1,000,431 sites"),
