@@ -67,14 +67,15 @@ WORKLOADS = {
     "4M": (1860.0, "square film 1860 xi, 3,998,502 sites"),
     # BASELINE config 4: strip with two current terminals (short edges), I = 0.2 * Ly, zero field
     "strip500k": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly"),
+    "strip120k": ((640.0, 164.0), "strip 640 x 164 xi, ~121k sites, two current terminals, I = 0.2 Ly"),
     "strip250k": ((920.0, 236.0), "strip 920 x 236 xi, ~251k sites, two current terminals, I = 0.2 Ly"),
     # the same strip just above the depairing current density (2 / (3 sqrt 3) = 0.385 in these units)
     "strip500k_ps": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.39 Ly (just above the depairing current)"),
     # ... and in a perpendicular field with the sub-critical current: vortices enter at the long edges and are driven across (flux flow)
     "strip500k_ff": ((1300.0, 333.0), "strip 1300 x 333 xi, 501,077 sites, two current terminals, I = 0.2 Ly, uniform field b = 0.02 (flux flow)"),
 }
-STRIP_CURRENT = {"strip250k": 0.2, "strip500k": 0.2, "strip500k_ps": 0.39, "strip500k_ff": 0.2}
-STRIP_FIELD = {"strip250k": 0.0, "strip500k": 0.0, "strip500k_ps": 0.0, "strip500k_ff": 0.02}
+STRIP_CURRENT = {"strip120k": 0.2, "strip250k": 0.2, "strip500k": 0.2, "strip500k_ps": 0.39, "strip500k_ff": 0.2}
+STRIP_FIELD = {"strip120k": 0.0, "strip250k": 0.0, "strip500k": 0.0, "strip500k_ps": 0.0, "strip500k_ff": 0.02}
 B_FIELD = 0.1  # B / Bc2
 
 
