@@ -260,7 +260,7 @@ typedef struct {
     const int32_t *sep_ptr;   /* [n_parts + 1] into sep_idx                                     */
     const int32_t *sep_idx;   /* separator-local indices of the sites part p touches            */
     const int64_t *e_off;     /* [n_parts] offset of E_p (n_p x s_p, row major) in e_vals       */
-    const double *e_vals;
+    const double *e_vals;     /* (checked for its size only: the way up reads the pool's -E_p^T blocks) */
     int64_t n_e;
     const double *u;          /* [n_sep]  -sum_p E_p^T 1                                        */
     const double *schur;      /* [n_sep, n_sep] row major                                       */
