@@ -397,7 +397,8 @@ def main():
     if args.sub_limits:
         from tdgl_amd.hipcore import TDGLContext
 
-        for name, v in zip(("SUB_MAX_SITES", "SUB2_MAX_SITES", "SUB2_BLOCK", "SUB2_SUPER", "SUB2_SPARSE_SEP_MIN_SITES"),
+        for name, v in zip(("SUB_MAX_SITES", "SUB2_MAX_SITES", "SUB2_BLOCK", "SUB2_SUPER", "SUB2_SPARSE_SEP_MIN_SITES", "SUB3_MIN_SITES",
+                            "SUB3_BIG"),
                            args.sub_limits.split(",")):
             if v:
                 setattr(TDGLContext, name, int(v))
@@ -545,10 +546,11 @@ def main():
                                          parts=sub["parts"], separator=sub["separator"], built_on=sub["built_on"],
                                          mb_per_solve=round(sub["bytes_per_solve"] / 1e6, 1))
             setup["mu_solver"] = "direct (substructured: dense interior blocks + dense Schur complement)"
-            if sub.get("levels") == 2:
-                setup["substructure"].update(levels=2, super_blocks=sub["super_blocks"], top_separator=sub["top_separator"])
-                setup["mu_solver"] = ("direct (two levels of nested dissection: dense part interiors, dense fine separators per "
-                                      "super-block, dense Schur complement of the top separator)")
+            if sub.get("levels", 1) >= 2:
+                setup["substructure"].update(levels=sub["levels"], super_blocks=sub["super_blocks"], top_separator=sub["top_separator"],
+                                             **({k: sub[k] for k in ("super_super_blocks", "top_top_separator") if k in sub}))
+                setup["mu_solver"] = (f"direct ({'two' if sub['levels'] == 2 else 'three'} levels of nested dissection: dense part interiors, "
+                                      "dense separators per block of the level above, dense Schur complement of the top separator)")
         elif getattr(ctx, "dense_direct", False):  # small meshes: explicit pseudo-inverse, built on the device (or the host's LAPACK)
             setup["dense_inverse"] = round(st.get("dense_inverse_device", 0.0) + st.get("dense_inverse_host", 0.0), 2)
             setup["dense_inverse_on"] = "device" if "dense_inverse_device" in st else "host"
@@ -903,7 +905,7 @@ def main():
         solve_bytes = int(sub["bytes_per_solve"]) if sub else nt * (nt + 1) // 2 * 128 * 128 * 8
         avg_ms = main_run.axp[1] / main_run.axp[0]
         roofline_direct = dict(
-            bound="hbm", kernel="direct mu solve: " + ("k_sub_down x 2 + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x 2" if sub and sub.get("levels") == 2 else
+            bound="hbm", kernel="direct mu solve: " + (f"k_sub_down x {sub['levels']} + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x {sub['levels']}" if sub and sub.get("levels", 1) >= 2 else
                                                        "k_sub_down + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up" if sub else
                                                        "k_dense_sym_tiles + k_dense_sym_finish"),
             achieved=round(solve_bytes / (avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",

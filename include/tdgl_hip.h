@@ -267,7 +267,7 @@ typedef struct {
 } tdgl_substructure;
 int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, double *seconds);
 /* Second level of the nested dissection, for meshes whose first-level separator is too large for a dense
- * matrix (~32k to ~480k sites).  Site order: part interiors, then the fine separators S'_Q of the Q
+ * matrix (~32k to ~650k sites).  Site order: part interiors, then the fine separators S'_Q of the Q
  * super-blocks (the parts of a super-block lie inside it), then the top separator T, which covers every
  * edge between two super-blocks (host layer: substructure.py: substructure_order2).  The first level is set
  * with tdgl_poisson_set_substructure and `schur == NULL` (n_sep = |S'| + |T|; its `u` is not used); this call
@@ -279,7 +279,11 @@ int tdgl_poisson_set_substructure(tdgl_ctx *ctx, const tdgl_substructure *s, dou
  * u = v_T - sum_q E_q^T v_q with v = 1_S - sum_p E_p^T 1 of the first level, so that
  * sum x = sum_p (G_p 1)^T b_p + sum_q (G_q v_q)^T r_q + u^T x_T.  A solve is six launches (down, down, the
  * dense pair on T, up, up); the time loop, the run-ahead loop and the in-loop guard use it like the one-level
- * form.  Until this call has succeeded the context keeps solving with AMG-PCG. */
+ * form.  Until this call has succeeded the context keeps solving with AMG-PCG.
+ * THREE levels: call it twice -- first with `schur == NULL` (the second level, whose separator T is then cut once more:
+ * super-super-blocks, parts T'_R, top-top separator TT; order ... | T'_0 .. | TT), then with the third level on the
+ * second level's Schur complement (n_interior = |T'|, n_sep = |TT|, functional = the second level's u), which
+ * carries the dense `schur`.  The last level given is the one with the dense matrix. */
 int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *inner, double *seconds);
 /* Optional, per level (0: the first, 1: the second): the sparse coupling block of the level's matrix, separator rows x
  * interior columns (A_SI as CSR [n_sep, n_interior]; for the second level S1_TS').  The level's separator right-hand

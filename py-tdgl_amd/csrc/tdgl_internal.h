@@ -363,9 +363,10 @@ struct tdgl_ctx {
     tdgl::DevBuf<double> sub_xs;          // [n_sep] separator solution before the mean is removed
     tdgl::DevBuf<double> sub_upart;       // per-workgroup partials of u . x_S
     int sub_nfin = 0;                     // workgroups of k_dense_sym_finish
-    // second level (tdgl_poisson_set_substructure_inner): the same construction on the first level's Schur
-    // complement -- its "parts" are the fine separators of the super-blocks, its separator the top separator T,
-    // whose pseudo-inverse is then the matrix in denseG (dense_n = |T|).  parts == 0: one level.
+    // further levels (tdgl_poisson_set_substructure_inner, once or twice): the same construction on the previous level's
+    // Schur complement -- the second level's "parts" are the fine separators of the super-blocks, its separator the top
+    // separator T; a third level cuts T the same way.  The LAST level's separator is the one whose pseudo-inverse is the
+    // matrix in denseG.  sub_n_inner == 0: one level.
     struct SubInner {
         int32_t parts = 0;
         int64_t nI = 0, nS = 0;           // fine-separator sites / |T|; nI + nS = sub_nS
@@ -378,7 +379,9 @@ struct tdgl_ctx {
         tdgl::DevBuf<double> w;           // [sub_nS + parts] way down of the second level
         tdgl::DevBuf<double> xt;          // [|T|] top separator solution
         tdgl::Csr coupling;               // (optional) S1_TS' [|T| x nI]: r_T = r_T - coupling y_q, see sub_coupling
-    } sub2;
+    } sub_in[2];
+    int sub_n_inner = 0;                  // inner levels set so far (the last one carries the dense top separator)
+    int sub_outer_parts_pending = 0;      // parts of the first level while it waits for its inner levels
     tdgl::DevBuf<tdgl::SubUpChunk> sub_chunks;
     tdgl::DevBuf<tdgl::SubDownChunk> sub_down_chunks;
     tdgl::DevBuf<tdgl::SubDownRow> sub_down_rows;
@@ -386,7 +389,7 @@ struct tdgl_ctx {
     // (optional, tdgl_poisson_set_substructure_coupling) A_SI [sub_nS x sub_nI]: the separator right-hand side of the way
     // down as r_S = b_S - A_SI y_I, a sparse product behind the dense one, instead of the -E_p^T rows inside it
     tdgl::Csr sub_coupling;
-    bool sub_need_coupling[2] = {false, false};  // a level was described without its -E^T rows and its coupling block is not there yet
+    bool sub_need_coupling[3] = {false, false, false};  // a level was described without its -E^T rows and its coupling block is not there yet
     // Solver choice in the time loop (tdgl_direct_switching; meshes where BOTH a direct solve and the hierarchy are
     // resident and large enough for the choice to matter).  A direct solve costs the same whatever the state; AMG-PCG
     // started from the projection guess costs next to nothing once the state is stationary (a transport current

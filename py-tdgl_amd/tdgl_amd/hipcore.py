@@ -91,6 +91,7 @@ class TDGLContext:
             reorder = None
         self._sub_part_ptr = None
         self._sub_super_ptr = None
+        self._sub_big_ptr = None
         self.direct_solve = bool(direct_solve)
         if reorder == "rcm":
             with _Stopwatch(self.setup_times, "reorder"):
@@ -104,9 +105,16 @@ class TDGLContext:
                     rank = np.empty(self.n, dtype=np.int64)
                     rank[perm] = np.arange(self.n)
                     block2 = self.SUB2_BLOCK or (128 if self.n < 200_000 else 160)
-                    super2 = self.SUB2_SUPER or max(2048, self.n // 60)
-                    perm, self._sub_part_ptr, self._sub_super_ptr = substructure_order2(
-                        np.asarray(mesh.sites), em.edges, block2, super2, rank_hint=rank)
+                    if self.n >= self.SUB3_MIN_SITES:
+                        # ... and three levels: one more cut above, so that the dense top separator stays small
+                        from .substructure import substructure_order3
+
+                        perm, self._sub_part_ptr, self._sub_super_ptr, self._sub_big_ptr = substructure_order3(
+                            np.asarray(mesh.sites), em.edges, block2, self.SUB2_SUPER or 4096, self.SUB3_BIG, rank_hint=rank)
+                    else:
+                        super2 = self.SUB2_SUPER or max(2048, self.n // 60)
+                        perm, self._sub_part_ptr, self._sub_super_ptr = substructure_order2(
+                            np.asarray(mesh.sites), em.edges, block2, super2, rank_hint=rank)
                 elif self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
                     # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
                     # then the separator" as the site order (substructure.py); inside a part the sites keep
@@ -186,12 +194,20 @@ class TDGLContext:
     # (SUB_MAX_SITES = 0 switches both forms off)
     # Upper limit: the direct solve costs the same whatever the state, AMG-PCG as much as mu is unpredictable -- 350k
     # sites 3.0k against 2.0k steps/s, 450k 2.3k against 1.9k in an evolving vortex state; the 500k-site strip with terminals
-    # in its STATIONARY state (an exact guess, 1.5 iterations) 1.8k against 3.8k; estimated crossover for evolving states ~550k.
-    SUB2_MAX_SITES = 480_000
+    # in its STATIONARY state (an exact guess, 1.5 iterations) 1.8k against 3.8k -- which the time loop notices by itself
+    # (`tdgl_direct_switching`); with three levels from 350k sites on: 600k sites 2.06k against 1.58k.
+    SUB2_MAX_SITES = 650_000
     # from here on the separator right-hand sides of the way down come from the sparse coupling blocks (two more
     # launches, no -E^T rows: `tdgl_poisson_set_substructure_coupling`)
     # (measured: 60k sites 13.0k against 13.6k steps/s, 120k 7.5k / 8.1k, 160k 5.9k / 6.2k, 250k 4.1k / 3.9k)
     SUB2_SPARSE_SEP_MIN_SITES = 200_000
+    # from here on a THIRD level (super-super-blocks of SUB3_BIG sites above the super-blocks, which then stay at 4,096
+    # sites): the dense top separator of two levels is a third of the bytes there (240 of 758 MB per solve at 250k
+    # sites; with three levels 29 + 23 + 22 MB)
+    # (measured, steps/s with two / three levels: 250k sites 4.30k / 4.28k -- 766 against 609 MB per solve, three more
+    # launches --, 450k sites 2.26k / 2.64k, 1.72 against 1.16 GB; 600k sites: 2.06k with three levels, AMG-PCG 1.58k)
+    SUB3_MIN_SITES = 350_000
+    SUB3_BIG = 32768
     # from here on the time loop may pause the direct solve in stationary states (`tdgl_direct_switching`): a 251k-site
     # strip with a transport current runs 7.1k steps/s on AMG-PCG (0 iterations) against 4.3k on the direct solve; below
     # ~150k sites the iterative step is launch-bound and the direct solve wins in every state
@@ -297,7 +313,42 @@ class TDGLContext:
                 n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=None if pk["schur"] is None else p_f64(pk["schur"]),
             )
 
-        if self._sub_super_ptr is not None:
+        if self._sub_big_ptr is not None:
+            # three levels: the factors are formed on the host, the top separator's pseudo-inverse on the device
+            from .substructure import build_substructure_levels
+
+            with _Stopwatch(self.setup_times, "substructure_host"):
+                try:
+                    levels = build_substructure_levels(A, [self._sub_part_ptr, self._sub_super_ptr, self._sub_big_ptr])
+                    packed = [pack_for_device(lv, True) for lv in levels]
+                except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
+                    self.setup_times["substructure_error"] = repr(exc)
+                    return False
+            t_dev = 0.0
+            status = _lib.TDGL_OK
+            for k, pk in enumerate(packed):
+                call = self._lib.tdgl_poisson_set_substructure if k == 0 else self._lib.tdgl_poisson_set_substructure_inner
+                status = call(self._ctx, C.byref(describe(pk)), C.byref(sec))
+                t_dev += sec.value
+                if status != _lib.TDGL_OK:
+                    break
+            if status == _lib.TDGL_OK:
+                for k, lv in enumerate(levels):
+                    M = lv.coupling
+                    keep_c = (i32(M.indptr), i32(M.indices), f64(M.data))
+                    status = self._lib.tdgl_poisson_set_substructure_coupling(self._ctx, k, p_i32(keep_c[0]), p_i32(keep_c[1]),
+                                                                              p_f64(keep_c[2]))
+                    if status != _lib.TDGL_OK:
+                        break
+            sec = C.c_double(t_dev)
+            sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
+            info = dict(levels=3, sparse_separator_rhs=True, parts=levels[0].n_parts, separator=levels[0].n_sep,
+                        super_blocks=levels[1].n_parts, top_separator=levels[1].n_sep, super_super_blocks=levels[2].n_parts,
+                        top_top_separator=levels[2].n_sep, built_on="host",
+                        bytes_per_solve=int(sum(8 * g.size for lv in levels for g in lv.G) + sum(8 * e.size for lv in levels for e in lv.E)
+                                            + 12 * sum(lv.coupling.nnz for lv in levels) + sym(levels[2].n_sep)))
+            del levels, packed
+        elif self._sub_super_ptr is not None:
             # two levels: the factors of both are formed on the host, the top separator's pseudo-inverse on the device
             from .substructure import build_substructure2
 
@@ -358,6 +409,8 @@ class TDGLContext:
             status = self._lib.tdgl_poisson_set_substructure(self._ctx, C.byref(describe(pk)), C.byref(sec))
             info = dict(parts=sub.n_parts, separator=sub.n_sep, bytes_per_solve=sub.bytes_per_solve(), built_on="host")
         if status != _lib.TDGL_OK:
+            err = self._lib.tdgl_last_error(self._ctx)
+            self.setup_times["substructure_error"] = err.decode() if isinstance(err, bytes) else str(err)
             return False
         self.setup_times["substructure_device"] = sec.value
         if not self._direct_solve_passes(check_rtol):

@@ -290,6 +290,122 @@ def solve_host2(sub2: Substructure2, b: np.ndarray, spinv: np.ndarray = None, re
     return x
 
 
+def substructure_order3(sites: np.ndarray, edges: np.ndarray, target_block: int = 160, target_super: int = 4096,
+                        target_big: int = 32768, rank_hint=None):
+    """Three levels: like `substructure_order2` with one more cut above it -- super-super-blocks of ``target_big`` sites
+    with a top-top separator TT, super-blocks inside them with separators T'_R, parts inside those with fine separators
+    S'_Q.  Order: part interiors | S'_0 .. | T'_0 .. | TT.  Returns ``perm`` and the three pointer arrays (part interiors;
+    the S'_Q; the T'_R: each [count + 1], in internal numbering, each starting where the previous one ends)."""
+    sites = np.asarray(sites, dtype=float)
+    n = len(sites)
+    i, j = edges[:, 0], edges[:, 1]
+
+    def cover(label, active):  # the endpoint with the lower label of every edge between two labels among the active sites
+        m = active[i] & active[j]
+        out = np.zeros(n, dtype=bool)
+        out[i[m & (label[i] < label[j])]] = True
+        out[j[m & (label[j] < label[i])]] = True
+        return out
+
+    def cut_inside(label_of_groups, n_groups, excluded, target):
+        lab = np.full(n, -1, dtype=np.int64)
+        count = 0
+        for g in range(n_groups):
+            idx = np.flatnonzero((label_of_groups == g) & ~excluded)
+            if len(idx) == 0:
+                continue
+            k = max(1, int(round(len(idx) / float(target))))
+            lab[idx] = count + (rcb_partition(sites[idx], k) if k > 1 else 0)
+            count += k
+        return lab, count
+
+    n_big = max(2, int(round(n / float(target_big))))
+    big = rcb_partition(sites, n_big).astype(np.int64)
+    is_TT = cover(big, np.ones(n, dtype=bool))
+    sup, n_sup = cut_inside(big, n_big, is_TT, target_super)
+    is_T = cover(sup, ~is_TT)
+    part, n_part = cut_inside(sup, n_sup, is_TT | is_T, target_block)
+    is_S = cover(part, ~is_TT & ~is_T)
+    key = np.arange(n) if rank_hint is None else np.asarray(rank_hint)
+    group = np.where(is_TT, n_part + n_sup + n_big, np.where(is_T, n_part + n_sup + big, np.where(is_S, n_part + sup, part)))
+    perm = np.lexsort((key, group)).astype(np.int32)
+    counts = np.bincount(group, minlength=n_part + n_sup + n_big + 1)
+    ptr1 = np.concatenate([[0], np.cumsum(counts[:n_part])]).astype(np.int32)
+    ptr2 = (ptr1[-1] + np.concatenate([[0], np.cumsum(counts[n_part:n_part + n_sup])])).astype(np.int32)
+    ptr3 = (ptr2[-1] + np.concatenate([[0], np.cumsum(counts[n_part + n_sup:n_part + n_sup + n_big])])).astype(np.int32)
+    return perm, ptr1, ptr2, ptr3
+
+
+def _schur_sparse(level: Substructure, A_level: sp.spmatrix) -> sp.csr_matrix:
+    """A level's Schur complement ``A_SS - sum_p A_Sp E_p`` as a sparse matrix (its blocks do not overlap outside the
+    next level's separator); consumes ``level.C``."""
+    nI = level.n_interior
+    rows, cols, vals = [], [], []
+    for idx, C in zip(level.sep_idx, level.C):
+        k = len(idx)
+        rows.append(np.repeat(idx, k))
+        cols.append(np.tile(idx, k))
+        vals.append(-C.ravel())
+    ASS = A_level[nI:, nI:].tocoo()
+    rows.append(ASS.row)
+    cols.append(ASS.col)
+    vals.append(ASS.data)
+    nS = A_level.shape[0] - nI
+    S = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nS, nS)).tocsr()
+    level.C = None
+    return (0.5 * (S + S.T)).tocsr()
+
+
+def build_substructure_levels(A: sp.spmatrix, ptrs) -> List[Substructure]:
+    """Factors of a dissection with ``len(ptrs)`` levels (pointer arrays as `substructure_order3` returns them): level
+    k is `build_substructure` applied to level k - 1's Schur complement, the gauge functional is handed down as weights,
+    only the last level forms its Schur complement densely; every level carries its sparse ``coupling`` block."""
+    A_level = A.tocsr()
+    levels, weights, offset = [], None, 0
+    for k, ptr in enumerate(ptrs):
+        last = k == len(ptrs) - 1
+        lv = build_substructure(A_level, np.asarray(ptr, dtype=np.int64) - offset, weights=weights, with_schur=last)
+        nI = lv.n_interior
+        lv.coupling = A_level[nI:, :nI].tocsr()
+        levels.append(lv)
+        if not last:
+            weights = (1.0 + lv.u) if k == 0 else lv.u  # (first level: v = 1_S - sum E^T 1; further down: u itself is the functional)
+            A_level = _schur_sparse(lv, A_level)
+            offset += nI
+    return levels
+
+
+def solve_host_levels(levels: List[Substructure], b: np.ndarray, sparse_sep: bool = True) -> np.ndarray:
+    """The multi-level device sequence in NumPy: ways down, the dense top separator, ways up, the mean removed."""
+    n = levels[0].n
+    vec = b - b.mean()
+    ys, total = [], 0.0
+    for lv in levels:
+        nI = lv.n_interior
+        y = np.empty(nI)
+        r = vec[nI:].copy()
+        for p in range(lv.n_parts):
+            a, e = int(lv.part_ptr[p]), int(lv.part_ptr[p + 1])
+            y[a:e] = lv.G[p] @ vec[a:e]
+            if not sparse_sep:
+                r[lv.sep_idx[p]] -= lv.E[p].T @ vec[a:e]
+            total += lv.g[a:e] @ vec[a:e]
+        if sparse_sep:
+            r -= lv.coupling @ y
+        ys.append(y)
+        vec = r
+    x = schur_pinv(levels[-1].schur) @ vec
+    total += levels[-1].u @ x
+    for lv, y in zip(reversed(levels), reversed(ys)):
+        full = np.empty(lv.n)
+        for p in range(lv.n_parts):
+            a, e = int(lv.part_ptr[p]), int(lv.part_ptr[p + 1])
+            full[a:e] = y[a:e] - lv.E[p] @ x[lv.sep_idx[p]]
+        full[lv.n_interior:] = x
+        x = full
+    return x - total / n
+
+
 def schur_pinv(schur: np.ndarray) -> np.ndarray:
     """pinv of the singular Schur complement (null space = constants), as `amg.dense_pseudo_inverse` does."""
     m = schur.shape[0]

@@ -97,4 +97,16 @@ def two_level_solve(monkeypatch):
     monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", 10 ** 9)
     monkeypatch.setattr(TDGLContext, "SUB2_BLOCK", 60)
     monkeypatch.setattr(TDGLContext, "SUB2_SUPER", 500)
+    monkeypatch.setattr(TDGLContext, "SUB3_MIN_SITES", 10 ** 9)
+    return 60
+
+
+@pytest.fixture
+def three_level_solve(two_level_solve, monkeypatch):
+    """... and from 200 sites up three levels (parts of ~60 sites, super-blocks of ~500, super-super-blocks of ~3,000),
+    which the product uses from `SUB3_MIN_SITES` on."""
+    from tdgl_amd.hipcore import TDGLContext
+
+    monkeypatch.setattr(TDGLContext, "SUB3_MIN_SITES", 200)
+    monkeypatch.setattr(TDGLContext, "SUB3_BIG", 3000)
     return 60
