@@ -1172,6 +1172,37 @@ def test_two_level_substructured_solve_on_the_host():
     assert np.abs((ws[q.n_interior:q.n_interior + q.n_sep] - q.coupling @ ws[:q.n_interior]) - rT).max() < 1e-11 * np.abs(rT).max()
 
 
+def test_three_level_substructured_solve_on_the_host():
+    """`substructure_order3` / `build_substructure_levels` / `solve_host_levels`: one more cut above the two-level form -- the
+    parts of every level are decoupled in the previous level's Schur complement, level k is the first level's
+    construction applied to it with the gauge functional handed down as weights, and the sequence returns pinv(A) b with
+    either form of the separator right-hand sides."""
+    from tdgl_amd.amg import exact_pinv
+    from tdgl_amd.hipcore import poisson_matrix
+    from tdgl_amd.substructure import build_substructure_levels, pack_for_device, solve_host_levels, substructure_order3
+
+    mesh = synthetic_mesh(60)
+    em = mesh.edge_mesh
+    n = len(mesh.sites)
+    perm, p1, p2, p3 = substructure_order3(mesh.sites, em.edges, 50, 350, 1500)
+    assert sorted(perm.tolist()) == list(range(n)) and p1[0] == 0 and p2[0] == p1[-1] and p3[0] == p2[-1] and p3[-1] < n
+    assert len(p3) - 1 >= 2 and len(p2) - 1 >= 3 * (len(p3) - 1) and len(p1) - 1 >= 3 * (len(p2) - 1)
+    iperm = np.empty(n, dtype=np.int64)
+    iperm[perm] = np.arange(n)
+    A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, n, iperm)
+    levels = build_substructure_levels(A, [p1, p2, p3])  # (raises when two parts of a level are coupled)
+    assert [lv.schur is None for lv in levels] == [True, True, False]
+    assert levels[1].n == levels[0].n_sep and levels[2].n == levels[1].n_sep
+    assert all(lv.coupling.shape == (lv.n_sep, lv.n_interior) for lv in levels)
+    b = np.random.default_rng(8).standard_normal(n)
+    want = exact_pinv(A) @ (b - b.mean())
+    for sparse_sep in (True, False):
+        x = solve_host_levels(levels, b, sparse_sep)
+        assert np.abs(x - want).max() < 1e-11 * np.abs(want).max() and abs(x.mean()) < 1e-14
+    pk = pack_for_device(levels[2], True)
+    assert pk["schur"].shape == (levels[2].n_sep, levels[2].n_sep) and pack_for_device(levels[1], True)["schur"] is None
+
+
 # ---------------------------------------------------------------- native mesh set-up (include/tdgl_host_mesh.h)
 def _triangle_set(tri):
     tri = np.sort(np.asarray(tri), axis=1)
