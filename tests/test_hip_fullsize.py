@@ -118,17 +118,22 @@ def test_config4_strip_500k_current_conservation_and_poisson_residual():
 _ORACLE_250K = {}
 
 
-@pytest.mark.parametrize("mu_solver", ["amg_pcg", "product_default"])
-def test_config2_250k_uniform_field_first_steps_match_oracle(mu_solver, request):
+@pytest.mark.parametrize("mu_solver", ["amg_pcg", "product_default", "three_levels"])
+def test_config2_250k_uniform_field_first_steps_match_oracle(mu_solver, request, monkeypatch):
     """BASELINE config 2 (250,510 sites, b = 0.1): 12 steps against the oracle (SuperLU), with the iterative mu solve
-    and with the product default at this size (the two-level direct solve: ~1,500 parts in 61 super-blocks)."""
+    with the product default at this size (the two-level direct solve: ~1,500 parts in 61 super-blocks) and with the three-level
+    form the product uses from 350k sites on."""
     from types import SimpleNamespace
 
     from oracle import OracleSolver, run_time_loop
     from tdgl_amd import SolverOptions, TDGLSolver
 
-    if mu_solver == "product_default":
+    if mu_solver != "amg_pcg":
         request.getfixturevalue("direct_solve")
+    if mu_solver == "three_levels":  # (the product's form from 350k sites on)
+        from tdgl_amd.hipcore import TDGLContext
+
+        monkeypatch.setattr(TDGLContext, "SUB3_MIN_SITES", 200_000)
     mesh = synthetic_mesh(465)
     assert len(mesh.sites) == 250510
     A = uniform_field_A(mesh, 0.1)
@@ -136,12 +141,14 @@ def test_config2_250k_uniform_field_first_steps_match_oracle(mu_solver, request)
     solver = TDGLSolver.from_dimensionless(mesh, SolverOptions(**kw, pcg_rtol=1e-11), A, 1.0, U_DEFAULT, GAMMA_DEFAULT)
     ctx = solver.ctx
     sub = ctx.substructure
-    assert (sub is not None and sub["levels"] == 2 and sub["super_blocks"] > 40) == (mu_solver == "product_default")
+    want_levels = dict(amg_pcg=0, product_default=2, three_levels=3)[mu_solver]
+    assert (0 if sub is None else sub["levels"]) == want_levels and (sub is None or sub["super_blocks"] > 40)
+    assert want_levels < 3 or sub["super_super_blocks"] >= 6
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     res = ctx.run(12)
     got = ctx.get_state()
-    assert (res["pcg_iters"].max() == 0) == (mu_solver == "product_default")
+    assert (res["pcg_iters"].max() == 0) == (mu_solver != "amg_pcg")
     ctx.close()
     if "want" not in _ORACLE_250K:
         o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
