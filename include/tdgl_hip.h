@@ -296,7 +296,8 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
  * solve costs the same whatever the state; AMG-PCG from the projection guess costs next to nothing once the state is
  * stationary (a transport current through a strip: 0 iterations) and more than the direct solve while vortices move
  * (251k-site strip, stationary: 7.1k against 4.3k steps/s; 250k-site film in a field: 2.4k against 4.3k).  on = 1: while
- * |psi|^2 has changed by less than 1e-4 per step for 64 accepted steps the direct solve is paused (one
+ * |psi|^2 has changed by less than 1e-4 per step for 64 accepted steps -- or has been falling by 10 % or more from one
+ * window of 64 steps to the next three times in a row, below 2e-3 -- the direct solve is paused (one
  * synchronisation per step, AMG-PCG); when the running mean of the PCG iterations exceeds 2.5 it comes back, and
  * the next pause has to wait twice as long (256 steps at first).  on = 0: off (the direct solve always); on < 0: query
  * only.  *switches / *paused (may be NULL): changes so far, the current state.  The host layer switches it on from

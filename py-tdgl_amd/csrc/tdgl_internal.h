@@ -403,6 +403,7 @@ struct tdgl_ctx {
     int64_t direct_switches = 0;
     double direct_recent_dmax[64] = {0};   // ring of the last accepted steps' max d|psi|^2
     int64_t direct_recent_n = 0;
+    double direct_win_max[4] = {0, 0, 0, 0};  // maxima of the last four complete windows of 64 steps, oldest first
     double direct_pcg_ema = 0.0;
     bool sub_wait_inner = false;          // first level set without a Schur complement: not usable before the second is
     // run-ahead time loop (direct solves, static links): device-resident controller + per-step records
