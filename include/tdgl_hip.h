@@ -299,7 +299,7 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
  * |psi|^2 has changed by less than 1e-4 per step for 64 accepted steps -- or has been falling by 10 % or more from one
  * window of 64 steps to the next three times in a row, below 2e-3 -- the direct solve is paused (one
  * synchronisation per step, AMG-PCG); when the running mean of the PCG iterations exceeds 2.5 it comes back, and
- * the next pause has to wait twice as long (256 steps at first).  on = 0: off (the direct solve always); on < 0: query
+ * the next pause has to wait twice as long (256 steps at first, and again after every pause that lasted 1,024 steps or more).  on = 0: off (the direct solve always); on < 0: query
  * only.  *switches / *paused (may be NULL): changes so far, the current state.  The host layer switches it on from
  * 150k sites. */
 int tdgl_direct_switching(tdgl_ctx *ctx, int32_t on, int64_t *switches, int32_t *paused);
