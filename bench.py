@@ -310,6 +310,9 @@ def main():
                     help="run the coarse AMG levels kernel by kernel instead of through the collapsed operators")
     ap.add_argument("--tail-cycles", type=int, default=2,
                     help="V-cycles folded into the explicit operators of the tail level (1 = the plain cycle)")
+    ap.add_argument("--mu-precond", choices=["auto", "factors", "vcycle"], default="auto",
+                    help="0.65 - 1.3M sites: which preconditioner the CG of the mu solve uses -- auto (default): per solve the cheaper "
+                         "of the AMG V-cycle and the fp32-stored nested-dissection factors by predicted cost; factors / vcycle: always that one")
     ap.add_argument("--sub-limits", default="", help=argparse.SUPPRESS)  # "SUB_MAX,SUB2_MAX,SUB2_BLOCK,SUB2_SUPER" (tuning runs)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
@@ -394,6 +397,10 @@ def main():
 
     from tdgl_amd import SolverOptions, TDGLSolver
 
+    if args.mu_precond != "auto":
+        from tdgl_amd.hipcore import TDGLContext
+
+        TDGLContext.PD_CHOICE = dict(factors=1, vcycle=2)[args.mu_precond]
     if args.sub_limits:
         from tdgl_amd.hipcore import TDGLContext
 
@@ -557,6 +564,9 @@ def main():
             setup["mu_solver"] = "direct (dense pseudo-inverse)"
         else:
             setup["mu_solver"] = "amg_pcg"
+        pd = getattr(ctx, "precond_direct", None)
+        if pd:  # 0.65 - 1.3M sites: the three-level factors in fp32 as a second preconditioner of the CG
+            setup["precond_direct"] = dict(host=round(st.get("substructure_host", 0.0), 2), device=round(st.get("substructure_device", 0.0), 2), **pd)
         log(f"rank {rank}: {name} set-up {total_s:.1f} s {setup}; AMG levels {h.sizes}, "
             f"operator complexity {h.operator_complexity:.2f}")
         if not probed:
@@ -607,6 +617,8 @@ def main():
         ctx.profile_enable(True)
         ctx.comm_stats(reset=True)
         ctx.step_stats(reset=True)
+        if getattr(ctx, "precond_direct", None):
+            ctx.precond_direct_stats(reset=True)
         barrier()
         t_begin = time.perf_counter()
         res = ctx.run(args.steps)
@@ -616,6 +628,7 @@ def main():
         trace.append(res)
         launches, k1_ms = ctx.profile_read()
         axp_launches, axp_ms = ctx.profile_read_pcg() if not use_dd else (0, 0.0)
+        direct_solves, direct_ms = ctx.profile_read_direct() if not use_dd else (0, 0.0)
         ctx.profile_enable(False)
         work = ctx.step_stats()
         ev_over = ctx.profile_event_overhead(50)  # (after the timed region)
@@ -652,10 +665,11 @@ def main():
                                          "order of pcg_rtol if every exchanged value arrived where it belongs")
         out = SimpleNamespace(
             wl=wl, name=name, ctx=ctx, drun=drun, n=n, m=m, n_loc=n_loc, m_loc=m_loc, elapsed=elapsed, res=res,
-            k1=(launches, k1_ms), k1_burst_ms=k1_burst_ms, axp=(axp_launches, axp_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
+            k1=(launches, k1_ms), k1_burst_ms=k1_burst_ms, axp=(axp_launches, axp_ms), direct=(direct_solves, direct_ms), ev_over=ev_over, comm=comm, sizes=list(h.sizes), start_state=start_state,
             end_state=end_state, work=work, setup=setup, windows={}, conservation=conservation,
             stats=dict(ctx.poisson_stats(), guess=ctx.guess_stats(), batch_prediction=ctx.pcg_prediction_stats(),
-                       **(dict(direct_switching=ctx.direct_switching()) if getattr(ctx, "dense_direct", False) else {})),
+                       **(dict(direct_switching=ctx.direct_switching()) if getattr(ctx, "dense_direct", False) else {}),
+                       **(dict(preconditioner=ctx.precond_direct_stats()) if getattr(ctx, "precond_direct", None) else {})),
             overlap=ctx.comm_overlap() if use_dd else None,
             its_pre=float(np.concatenate([t["pcg_iters"] for t in trace[:-1]]).mean()) if len(trace) > 1 else None,
             trace=dict(dt=np.concatenate([t["dt"] for t in trace]).tolist(),
@@ -704,6 +718,8 @@ def main():
             rec["start"] = dict(psi=st["psi"], mu=st["mu"], step=ls0["step"], time=ls0["time"], dt=ls0["dt"],
                                 tentative_dt=cs0["tentative_dt"], history=cs0["history"])
         ctx.step_stats(reset=True)
+        if getattr(ctx, "precond_direct", None):
+            ctx.precond_direct_stats(reset=True)
         ctx.synchronize()
         t_begin = time.perf_counter()
         res = ctx.run(args.steps)
@@ -725,6 +741,7 @@ def main():
             dt=dict(mean=float(res["dt"].mean()), min=float(res["dt"].min()), max=float(res["dt"].max())),
             guess=ctx.guess_stats(),
             **(dict(direct_switching=ctx.direct_switching()) if getattr(ctx, "dense_direct", False) else {}),
+            **(dict(preconditioner=ctx.precond_direct_stats()) if getattr(ctx, "precond_direct", None) else {}),
         )
 
     def late_window(r):
@@ -897,20 +914,24 @@ def main():
     # direct mu solves (small / mid-size workloads): the solve's launches (k_dense_sym_tiles + k_dense_sym_finish, or
     # k_sub_down + those two + k_sub_up) bracketed by one event pair per batch of the run-ahead loop; bytes = the factors
     # streamed once per solve (the symmetric packing halves the dense inverse: what is moved, not n^2 * 8)
+    # (samples of the direct solve's own event pairs only: when the time loop has paused the direct solve --
+    # tdgl_direct_switching -- the timed window holds none and the object is null; the CG's A p samples of such a
+    # window are `roofline_pcg`)
     roofline_direct = None
-    if rank == 0 and main_run.axp[0] > 0 and main_run.setup.get("mu_solver", "amg_pcg") != "amg_pcg":
-        roofline_pcg = None
+    if rank == 0 and main_run.direct[0] > 0 and main_run.setup.get("mu_solver", "amg_pcg") != "amg_pcg":
+        if main_run.axp[0] == 0:
+            roofline_pcg = None
         sub = getattr(main_run.ctx, "substructure", None)
         nt = (main_run.n + 127) // 128
         solve_bytes = int(sub["bytes_per_solve"]) if sub else nt * (nt + 1) // 2 * 128 * 128 * 8
-        avg_ms = main_run.axp[1] / main_run.axp[0]
+        avg_ms = main_run.direct[1] / main_run.direct[0]
         roofline_direct = dict(
             bound="hbm", kernel="direct mu solve: " + (f"k_sub_down x {sub['levels']} + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x {sub['levels']}" if sub and sub.get("levels", 1) >= 2 else
                                                        "k_sub_down + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up" if sub else
                                                        "k_dense_sym_tiles + k_dense_sym_finish"),
             achieved=round(solve_bytes / (avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(solve_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), bytes_per_solve=solve_bytes,
-            avg_solve_ms=round(avg_ms, 5), samples=main_run.axp[0], event_pair_overhead_ms=round(main_run.ev_over, 5),
+            avg_solve_ms=round(avg_ms, 5), samples=main_run.direct[0], event_pair_overhead_ms=round(main_run.ev_over, 5),
             note="launch sequence bracketed by one HIP event pair per batch of the run-ahead loop (the pair's own overhead included)",
         )
     r = main_run

@@ -305,6 +305,28 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
 int tdgl_direct_switching(tdgl_ctx *ctx, int32_t on, int64_t *switches, int32_t *paused);
 int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const int32_t *indptr, const int32_t *indices,
                                            const double *data);
+/* The resident factors (every level and coupling block described) as the PRECONDITIONER of the CG instead of as the
+ * solver -- the counterpart of the reference's `mu_laplacian_lu(rhs)` (tdgl/solver/solver.py:516, factorised at
+ * tdgl/finite_volume/operators.py:305-308) for meshes of 0.65 - 1.3 million sites, where streaming the fp64 factors
+ * (2.9 GB at 1M sites) costs as much as the 7-12 AMG-preconditioned iterations it would replace:
+ *   - fp32_storage != 0: the value pools and the top separator's tiles are converted to fp32 (half the bytes; the
+ *     fp64 pools are released); every multiply-add stays fp64.  One application then contracts the residual by
+ *     ~1e-5 .. 1e-6 -- ONE CG iteration wherever the projection guess is good to 1e-4 --, and the CG around it (A p
+ *     with the fp64 matrix, recurrences, dot products, convergence test) is unchanged, so mu meets the same pcg_rtol;
+ *   - the context keeps ITS site order (reverse Cuthill-McKee: what the stencil kernels and the hierarchy are fastest
+ *     in); the factors were described in the dissection's order, and site_map[i] = the caller's site at dissection
+ *     position i ([n_sites], a permutation) lets an application gather the residual and scatter the result;
+ *   - per solve the library takes the cheaper of the two preconditioners by PREDICTED cost: the decades to go (the
+ *     residual of the projection guess, known on the host before anything is queued) over the decades per iteration
+ *     observed for each, times what one application was MEASURED to take on this device at this call (*t_apply_us for
+ *     the factors, *t_vcycle_us for the AMG V-cycle; may be NULL).
+ * tdgl_poisson_precond_choice: 0 = by predicted cost (default), 1 = always the factors, 2 = never (tests, A/B runs).
+ * tdgl_get_precond_direct_stats: out4 = {solves with the factors, their CG iterations, solves with the V-cycle, their
+ * iterations} since the last reset, out3 = {t_apply_us, t_vcycle_us, decades per application observed}. */
+int tdgl_poisson_set_substructure_precond(tdgl_ctx *ctx, const int32_t *site_map, int32_t fp32_storage, double *t_apply_us,
+                                          double *t_vcycle_us);
+int tdgl_poisson_precond_choice(tdgl_ctx *ctx, int32_t mode);
+int tdgl_get_precond_direct_stats(tdgl_ctx *ctx, int64_t *out4, double *out3, int32_t reset);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
  * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep
@@ -676,6 +698,10 @@ int tdgl_profile_read(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
 /* The same for the kernel that dominates the run time, the CG's fused direction update + A p
  * (k_sell_axp): every 8th launch after tdgl_profile_enable is timed, up to 64 samples (single GPU). */
 int tdgl_profile_read_pcg(tdgl_ctx *ctx, int64_t *launches, double *total_ms);
+/* ... and for the launch sequence of a direct mu solve: one event pair per batch of the run-ahead loop brackets the
+ * whole solve (k_sub_down ... k_sub_up / k_dense_sym_tiles + _finish).  Counted apart from the samples above, so
+ * that a window in which the time loop changed the solver (tdgl_direct_switching) reports each kind by itself. */
+int tdgl_profile_read_direct(tdgl_ctx *ctx, int64_t *solves, double *total_ms);
 /* Mean reading of an event pair with nothing recorded in between (the markers' own cost, which
  * the in-run durations above contain and a profiler's dispatch durations do not). */
 int tdgl_profile_event_overhead(tdgl_ctx *ctx, int32_t reps, double *avg_ms);

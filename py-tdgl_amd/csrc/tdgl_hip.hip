@@ -180,6 +180,10 @@ extern "C" void tdgl_destroy(tdgl_ctx *ctx) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (auto &pr : ctx->prof3_pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     hipStream_t s = ctx->stream;
     delete ctx;  // frees the DevBufs
@@ -1142,6 +1146,8 @@ extern "C" int tdgl_profile_enable(tdgl_ctx *ctx, int32_t on) {
     ctx->prof2_ms = 0.0;
     ctx->prof2_budget = on ? 64 : 0;
     ctx->prof2_seen = 0;
+    ctx->prof3_launches = 0;
+    ctx->prof3_ms = 0.0;
     return TDGL_OK;
 }
 
@@ -1166,6 +1172,16 @@ static int profile_drain(tdgl_ctx *ctx) {
         ctx->prof_pool.push_back(pr.second);
     }
     ctx->prof2_pending.clear();
+    for (auto &pr : ctx->prof3_pending) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventSynchronize(pr.second));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pr.first, pr.second));
+        ctx->prof3_ms += ms;
+        ctx->prof3_launches += 1;
+        ctx->prof_pool.push_back(pr.first);
+        ctx->prof_pool.push_back(pr.second);
+    }
+    ctx->prof3_pending.clear();
     return TDGL_OK;
 }
 
@@ -1174,6 +1190,14 @@ extern "C" int tdgl_profile_read_pcg(tdgl_ctx *ctx, int64_t *launches, double *t
     TDGL_TRY(profile_drain(ctx));
     if (launches) *launches = ctx->prof2_launches;
     if (total_ms) *total_ms = ctx->prof2_ms;
+    return TDGL_OK;
+}
+
+extern "C" int tdgl_profile_read_direct(tdgl_ctx *ctx, int64_t *solves, double *total_ms) {
+    CTX_GUARD(ctx);
+    TDGL_TRY(profile_drain(ctx));
+    if (solves) *solves = ctx->prof3_launches;
+    if (total_ms) *total_ms = ctx->prof3_ms;
     return TDGL_OK;
 }
 

@@ -373,6 +373,7 @@ struct tdgl_ctx {
         tdgl::DevBuf<int32_t> part_ptr, seg_ptr, seg_x, seg_len, sep_ptr, sep_idx, row_part;
         tdgl::DevBuf<int64_t> seg_val, e_off, g_off;
         tdgl::DevBuf<double> vals, e, u;
+        tdgl::DevBuf<float> vals32;       // (sub_fp32: the pool in fp32, `vals` released)
         tdgl::DevBuf<tdgl::SubUpChunk> chunks;
         tdgl::DevBuf<tdgl::SubDownChunk> down_chunks;
         tdgl::DevBuf<tdgl::SubDownRow> down_rows;
@@ -389,6 +390,25 @@ struct tdgl_ctx {
     // (optional, tdgl_poisson_set_substructure_coupling) A_SI [sub_nS x sub_nI]: the separator right-hand side of the way
     // down as r_S = b_S - A_SI y_I, a sparse product behind the dense one, instead of the -E_p^T rows inside it
     tdgl::Csr sub_coupling;
+    // The factors as the CG's PRECONDITIONER (tdgl_poisson_set_substructure_precond; 650k - 1.3M sites): value pools and
+    // the top separator's tiles stored in fp32 (sub_vals32 / SubInner::vals32 / denseG32; the fp64 pools are released),
+    // every multiply-add fp64; the context stays in reverse Cuthill-McKee order, the dissection order lives inside the
+    // application (sub_map[i] = the context's index of the site at dissection position i).  One application contracts
+    // the residual by ~1e-5 .. 1e-6 (the rounding of the stored entries), so the CG needs ONE iteration wherever the
+    // projection guess is good to 1e-4 -- at half the bytes of the fp64 factors.  pcg_solve chooses between this and the
+    // AMG V-cycle per solve, by predicted cost (iterations x measured time per application).
+    bool sub_precond = false;
+    bool sub_fp32 = false;
+    bool sub_lanes = false;               // the ways down run k_sub_down_lanes (chunk lists rebuilt for it)
+    bool sub_ident[3] = {false, false, false};  // level k's separator rows are their identity segment alone (out = b)
+    tdgl::DevBuf<float> sub_vals32, denseG32;
+    tdgl::DevBuf<int32_t> sub_map;
+    tdgl::DevBuf<double> sub_bp, sub_xp, sub_z;   // [n] gathered residual / solution in dissection order / z in the context's order
+    int32_t pd_choice = 0;                // 0: by predicted cost, 1: always the factors, 2: never (AMG V-cycle)
+    double pd_rate = 4.5;                 // decades per iteration observed with the factors as preconditioner (running mean)
+    double pd_t_apply_us = 0.0, pd_t_vcycle_us = 0.0;  // measured at set-up: one application of either preconditioner
+    int64_t pd_solves = 0, pd_iters = 0, pd_amg_solves = 0, pd_amg_iters = 0;  // solves / iterations by preconditioner since the last reset
+    bool pd_last = false;                 // the last solve used the factors
     bool sub_need_coupling[3] = {false, false, false};  // a level was described without its -E^T rows and its coupling block is not there yet
     // Solver choice in the time loop (tdgl_direct_switching; meshes where BOTH a direct solve and the hierarchy are
     // resident and large enough for the choice to matter).  A direct solve costs the same whatever the state; AMG-PCG
@@ -534,4 +554,9 @@ struct tdgl_ctx {
     int64_t prof2_launches = 0, prof2_budget = 0, prof2_seen = 0;
     double prof2_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof2_pending;
+    // ... and for the launch sequence of a direct mu solve (one pair per run-ahead batch; its own counters, so that a
+    // window in which the loop changed the solver does not divide one kind of bytes by the other kind of samples)
+    int64_t prof3_launches = 0;
+    double prof3_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof3_pending;
 };

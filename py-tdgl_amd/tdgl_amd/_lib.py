@@ -236,6 +236,9 @@ SIGNATURES = {
     "tdgl_poisson_set_substructure_inner": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
     "tdgl_direct_switching": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tdgl_poisson_set_substructure_coupling": (C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p]),
+    "tdgl_poisson_set_substructure_precond": (C.c_int, [_CTX, c_i32p, C.c_int32, c_f64p, c_f64p]),
+    "tdgl_poisson_precond_choice": (C.c_int, [_CTX, C.c_int32]),
+    "tdgl_get_precond_direct_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p, C.c_int32]),
     "tdgl_poisson_build_substructure": (C.c_int, [_CTX, C.POINTER(SubstructurePlan), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
     "tdgl_set_deep_halo_plan": (C.c_int, [_CTX, C.POINTER(DeepHaloPlan)]),
@@ -306,6 +309,7 @@ SIGNATURES = {
     "tdgl_time_kernel": (C.c_int, [_CTX, C.c_int32, C.c_int32, c_f64p]),
     "tdgl_profile_enable": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_profile_read_pcg": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
+    "tdgl_profile_read_direct": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
     "tdgl_profile_read": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p]),
     "tdgl_profile_event_overhead": (C.c_int, [_CTX, C.c_int32, c_f64p]),
     "tdgl_get_precond_storage": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),

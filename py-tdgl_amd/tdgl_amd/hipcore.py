@@ -92,6 +92,8 @@ class TDGLContext:
         self._sub_part_ptr = None
         self._sub_super_ptr = None
         self._sub_big_ptr = None
+        self._pd_order = None
+        self.precond_direct = None
         self.direct_solve = bool(direct_solve)
         if reorder == "rcm":
             with _Stopwatch(self.setup_times, "reorder"):
@@ -115,6 +117,16 @@ class TDGLContext:
                         super2 = self.SUB2_SUPER or max(2048, self.n // 60)
                         perm, self._sub_part_ptr, self._sub_super_ptr = substructure_order2(
                             np.asarray(mesh.sites), em.edges, block2, super2, rank_hint=rank)
+                elif self.direct_solve and 0 < self.SUB_MAX_SITES and max(self.SUB_MAX_SITES, self.SUB2_MAX_SITES) < self.n <= self.PD_MAX_SITES:
+                    # larger still: the context KEEPS the reverse Cuthill-McKee order (what the stencil kernels and the AMG
+                    # hierarchy are fastest in); three levels of dissection are cut all the same, their factors become the
+                    # CG's preconditioner and their order lives inside its application (`build_precond_direct`)
+                    from .substructure import substructure_order3
+
+                    rank = np.empty(self.n, dtype=np.int64)
+                    rank[perm] = np.arange(self.n)
+                    self._pd_order = substructure_order3(np.asarray(mesh.sites), em.edges, self.SUB2_BLOCK or 160,
+                                                         self.SUB2_SUPER or 4096, self.SUB3_BIG, rank_hint=rank)
                 elif self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
                     # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
                     # then the separator" as the site order (substructure.py); inside a part the sites keep
@@ -214,6 +226,12 @@ class TDGLContext:
     DIRECT_SWITCH_MIN_SITES = 150_000
     SUB2_BLOCK = 0
     SUB2_SUPER = 0
+    # above SUB2_MAX_SITES and up to here the three-level factors are built as well, stored in fp32, and PRECONDITION the
+    # CG (`tdgl_poisson_set_substructure_precond`): at 1M sites the fp64 factors are 2.9 GB per solve -- 700 us, what
+    # 7-8 AMG-preconditioned iterations cost --, in fp32 half of that buys five decades per application, i.e. ONE CG
+    # iteration from the projection guess.  Per solve the library takes the V-cycle or the factors by predicted cost.
+    PD_MAX_SITES = int(__import__("os").environ.get("TDGL_PD_MAX_SITES", "1300000"))
+    PD_CHOICE = 0  # 0: by predicted cost, 1: always the factors, 2: never (tests / A-B runs)
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
@@ -275,6 +293,8 @@ class TDGLContext:
         check = min(1e-11, float(rtol))
         if self.n_owned == self.n and self._sub_part_ptr is not None and dense_max_sites is None and self.direct_solve:
             self.build_substructure(A, check_rtol=check)
+        elif self.n_owned == self.n and self._pd_order is not None and dense_max_sites is None and self.direct_solve:
+            self.build_precond_direct(rtol=float(rtol))
         elif self.n_owned == self.n and 2 <= self.n <= limit:
             self.build_dense_inverse(A, check_rtol=check)
         return h
@@ -324,22 +344,7 @@ class TDGLContext:
                 except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
                     self.setup_times["substructure_error"] = repr(exc)
                     return False
-            t_dev = 0.0
-            status = _lib.TDGL_OK
-            for k, pk in enumerate(packed):
-                call = self._lib.tdgl_poisson_set_substructure if k == 0 else self._lib.tdgl_poisson_set_substructure_inner
-                status = call(self._ctx, C.byref(describe(pk)), C.byref(sec))
-                t_dev += sec.value
-                if status != _lib.TDGL_OK:
-                    break
-            if status == _lib.TDGL_OK:
-                for k, lv in enumerate(levels):
-                    M = lv.coupling
-                    keep_c = (i32(M.indptr), i32(M.indices), f64(M.data))
-                    status = self._lib.tdgl_poisson_set_substructure_coupling(self._ctx, k, p_i32(keep_c[0]), p_i32(keep_c[1]),
-                                                                              p_f64(keep_c[2]))
-                    if status != _lib.TDGL_OK:
-                        break
+            status, t_dev = self._upload_levels(levels, packed)
             sec = C.c_double(t_dev)
             sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
             info = dict(levels=3, sparse_separator_rhs=True, parts=levels[0].n_parts, separator=levels[0].n_sep,
@@ -422,6 +427,100 @@ class TDGLContext:
         if self.n >= self.DIRECT_SWITCH_MIN_SITES:
             self.direct_switching(True)
         return True
+
+    def _upload_levels(self, levels, packed):
+        """The factors of a multi-level dissection (`substructure.build_substructure_levels`, `pack_for_device(..., True)`)
+        into the library: first level, inner levels, every level's sparse coupling block.  Returns (status, device seconds)."""
+        sec = C.c_double(0.0)
+        p_i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+
+        def describe(pk):
+            return _lib.Substructure(
+                n_interior=pk["n_interior"], n_sep=pk["n_sep"], n_parts=pk["n_parts"], part_ptr=p_i32(pk["part_ptr"]),
+                seg_ptr=p_i32(pk["seg_ptr"]), seg_val=p_i64(pk["seg_val"]), seg_x=p_i32(pk["seg_x"]),
+                seg_len=p_i32(pk["seg_len"]), vals=p_f64(pk["vals"]), n_vals=len(pk["vals"]), sep_ptr=p_i32(pk["sep_ptr"]),
+                sep_idx=p_i32(pk["sep_idx"]), e_off=p_i64(pk["e_off"]), e_vals=p_f64(pk["e_vals"]),
+                n_e=len(pk["e_vals"]), u=p_f64(pk["u"]), schur=None if pk["schur"] is None else p_f64(pk["schur"]),
+            )
+
+        t_dev, status = 0.0, _lib.TDGL_OK
+        for k, pk in enumerate(packed):
+            call = self._lib.tdgl_poisson_set_substructure if k == 0 else self._lib.tdgl_poisson_set_substructure_inner
+            status = call(self._ctx, C.byref(describe(pk)), C.byref(sec))
+            t_dev += sec.value
+            if status != _lib.TDGL_OK:
+                return status, t_dev
+        for k, lv in enumerate(levels):
+            M = lv.coupling
+            keep_c = (i32(M.indptr), i32(M.indices), f64(M.data))
+            status = self._lib.tdgl_poisson_set_substructure_coupling(self._ctx, k, p_i32(keep_c[0]), p_i32(keep_c[1]), p_f64(keep_c[2]))
+            if status != _lib.TDGL_OK:
+                break
+        return status, t_dev
+
+    def build_precond_direct(self, rtol=1e-10) -> bool:
+        """Three levels of nested dissection as the CG's PRECONDITIONER (`tdgl_poisson_set_substructure_precond`; the
+        counterpart of the reference's LU, operators.py:305-308, above `SUB2_MAX_SITES`): factors formed on the host in
+        the dissection's order (`_pd_order`), stored in fp32 on the device, applied through a gather / scatter so that
+        the context keeps its reverse Cuthill-McKee order.  Checked on a white-noise right-hand side from a zero guess
+        (the CG must get to ``rtol`` in at most three applications); returns whether it is on."""
+        from .substructure import build_substructure_levels, pack_for_device
+
+        perm_d, p1, p2, p3 = self._pd_order
+        k = self._keep
+        iperm_d = np.empty(self.n, dtype=np.int64)
+        iperm_d[perm_d] = np.arange(self.n)
+        with _Stopwatch(self.setup_times, "substructure_host"):
+            try:
+                A_d = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, iperm_d)
+                levels = build_substructure_levels(A_d, [p1, p2, p3])
+                packed = [pack_for_device(lv, True) for lv in levels]
+            except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
+                self.setup_times["substructure_error"] = repr(exc)
+                return False
+        status, t_dev = self._upload_levels(levels, packed)
+        ta, tv = C.c_double(0.0), C.c_double(0.0)
+        if status == _lib.TDGL_OK:
+            keep_map = i32(perm_d)
+            status = self._lib.tdgl_poisson_set_substructure_precond(self._ctx, p_i32(keep_map), 1, C.byref(ta), C.byref(tv))
+        if status != _lib.TDGL_OK:
+            err = self._lib.tdgl_last_error(self._ctx)
+            self.setup_times["substructure_error"] = err.decode() if isinstance(err, bytes) else str(err)
+            self._chk(self._lib.tdgl_poisson_set_substructure(self._ctx, None, None))
+            return False
+        self.setup_times["substructure_device"] = t_dev
+        sym = lambda m: ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
+        entries = sum(g.size for lv in levels for g in lv.G) + sum(e.size for lv in levels for e in lv.E) + sym(levels[2].n_sep)
+        info = dict(levels=3, storage="fp32", parts=levels[0].n_parts, separator=levels[0].n_sep, super_blocks=levels[1].n_parts,
+                    top_separator=levels[1].n_sep, super_super_blocks=levels[2].n_parts, top_top_separator=levels[2].n_sep,
+                    bytes_per_application=int(4 * entries + 12 * sum(lv.coupling.nnz for lv in levels) + 2 * 20 * self.n),
+                    t_apply_us=round(ta.value, 1), t_vcycle_us=round(tv.value, 1))
+        del levels, packed
+        # the check: with the factors forced, a white-noise right-hand side from a zero guess
+        self._chk(self._lib.tdgl_poisson_precond_choice(self._ctx, 1))
+        b = np.random.default_rng(0).standard_normal(self.n)
+        _, its, relres = self.poisson_solve(b)
+        self._chk(self._lib.tdgl_poisson_precond_choice(self._ctx, int(self.PD_CHOICE)))
+        info.update(check_iterations=int(its), check_relres=float(relres))
+        if not (relres <= rtol and its <= 3):
+            self._chk(self._lib.tdgl_poisson_set_substructure(self._ctx, None, None))
+            self.setup_times["substructure_error"] = f"preconditioner check: {its} iterations, relres {relres:.2e}"
+            return False
+        self.precond_direct = info
+        self.precond_direct_stats(reset=True)
+        return True
+
+    def precond_direct_stats(self, reset=False):
+        """`tdgl_get_precond_direct_stats`: solves / CG iterations by preconditioner since the last reset, the measured
+        time per application of either, the decades per application observed with the factors."""
+        o4, o3 = (C.c_int64 * 4)(), (C.c_double * 3)()
+        self._chk(self._lib.tdgl_get_precond_direct_stats(self._ctx, o4, o3, int(bool(reset))))
+        return dict(solves_factors=int(o4[0]), iterations_factors=int(o4[1]), solves_vcycle=int(o4[2]), iterations_vcycle=int(o4[3]),
+                    t_apply_us=round(o3[0], 1), t_vcycle_us=round(o3[1], 1), decades_per_application=round(o3[2], 2))
+
+    def precond_choice(self, mode: int):
+        """0: the library chooses per solve by predicted cost, 1: always the factors, 2: always the AMG V-cycle."""
+        self._chk(self._lib.tdgl_poisson_precond_choice(self._ctx, int(mode)))
 
     def direct_switching(self, on=None):
         """`tdgl_direct_switching`: let the time loop pause the direct mu solve while the state is stationary (AMG-PCG
@@ -1208,6 +1307,13 @@ class TDGLContext:
     def profile_read_pcg(self):
         n, ms = C.c_int64(0), C.c_double(0)
         self._chk(self._lib.tdgl_profile_read_pcg(self._ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def profile_read_direct(self):
+        """(solves bracketed, their total milliseconds): the direct mu solve's launch sequence, one sample per
+        run-ahead batch since `profile_enable`."""
+        n, ms = C.c_int64(0), C.c_double(0)
+        self._chk(self._lib.tdgl_profile_read_direct(self._ctx, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
     def precond_storage(self) -> int:

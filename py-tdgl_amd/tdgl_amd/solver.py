@@ -610,7 +610,9 @@ class TDGLSolver:
                 mean_pcg_iterations=float(dynamics.pcg_iterations.mean()) if len(dynamics.pcg_iterations) else 0.0,
                 # which mu solve the mesh size selected (hipcore.TDGLContext.build_poisson)
                 mu_solver=("direct (substructured)" if getattr(self.ctx, "substructure", None) else
-                           "direct (dense inverse)" if getattr(self.ctx, "dense_direct", False) else "amg_pcg"),
+                           "direct (dense inverse)" if getattr(self.ctx, "dense_direct", False) else
+                           "pcg (AMG V-cycle or fp32-stored nested-dissection factors, by predicted cost)"
+                           if getattr(self.ctx, "precond_direct", None) else "amg_pcg"),
                 # the direct solves' in-loop guard: largest ||b - A mu|| / ||b|| over the checked steps
                 # (one per batch of queued attempts), how many were checked, and whether a check above
                 # 1e-9 sent the run back to AMG-PCG (never observed; the factors deliver 1e-14)

@@ -75,3 +75,22 @@ def test_single_gpu_line_carries_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
     assert d["parity_vs_oracle"]["ok"] and d["parity_vs_oracle"]["tolerance"] == 1e-8
+    # 59k sites: the two-level direct solve in the run-ahead loop -- its own roofline object, from its own event pairs
+    rd = d["roofline_direct"]
+    assert rd is not None and rd["samples"] >= 1 and 0.0 < rd["frac"] <= 1.0 and d["roofline_pcg"] is None
+    assert 0.0 < r["frac"] <= 1.0
+
+
+def test_a_window_in_which_the_loop_has_paused_the_direct_solve_reports_no_direct_roofline():
+    """The 251k-site strip relaxes into a stationary state; the time loop then pauses the direct mu solve
+    (`tdgl_direct_switching`) and AMG-PCG from the projection guess takes over.  A timed window in that state holds no
+    direct solve: `roofline_direct` must be null (round 5 divided the factors' bytes by event pairs that bracketed the
+    CG's `A p` kernel: frac 2.9), and no roofline object of the line may claim more than the peak."""
+    d = _run("--workload", "strip250k", "--steps", "20", "--warmup", "5", "--preroll", "1500", "--no-cpu-baseline",
+             "--vortex-window", "off")
+    sw = d["pcg"].get("direct_switching") or d.get("direct_switching")
+    assert sw is not None and sw["paused"] and sw["switches"] >= 1, d["pcg"]
+    assert d["roofline_direct"] is None
+    for key in ("roofline", "roofline_pcg"):
+        if d.get(key) is not None:
+            assert 0.0 < d[key]["frac"] <= 1.0, (key, d[key])

@@ -62,27 +62,65 @@ def _values_match_the_oracle(mesh, A, ctx, st, dt, fixed=None, mu_boundary=None,
                                                                     U_DEFAULT, 50.0, lap) is None)
 
 
-def test_config4_strip_500k_current_conservation_and_poisson_residual():
-    """BASELINE config 4: strip with two current terminals, ~500k sites, mu Poisson every step."""
+_ORACLE_STRIP = {}
+_STRIP_ORACLE_STEPS = 16
+
+
+@pytest.mark.parametrize("mu_solver", ["amg_pcg", "product_default"])
+def test_config4_strip_500k_current_conservation_and_poisson_residual(mu_solver, request):
+    """BASELINE config 4: strip with two current terminals, ~500k sites, mu Poisson every step -- with the iterative mu
+    solve and with what the product ships at this size (`product_default`: the three-level direct solve in the
+    run-ahead loop, with the loop's solver choice switched on).  Both: 16 steps against the oracle (SuperLU; terminals
+    and `mu_boundary`, solver.py:325-345, 489-520) at 1e-9 in dt, |psi|^2, mu - <mu>, J_s, J_n; then on to step 60 for
+    the size-independent checks."""
+    from types import SimpleNamespace
+
+    from oracle import OracleSolver, run_time_loop
     from tdgl_amd import SolverOptions, TDGLSolver
     from tdgl_amd.hipcore import poisson_matrix
 
+    if mu_solver == "product_default":
+        request.getfixturevalue("direct_solve")
     mesh = synthetic_mesh(1300, 333)  # 500,955 sites
     n = len(mesh.sites)
     assert 4.9e5 < n < 5.1e5
     terms = [edge_terminal(mesh, "source", -650.0), edge_terminal(mesh, "drain", 650.0)]
     current = 0.2 * 333  # SURVEY.md section 8(d): I = 0.2 * Ly
-    opts = SolverOptions(solve_time=1e9, dt_init=1e-4, save_every=10**6)
+    kw = dict(solve_time=1e9, dt_init=1e-4, save_every=10**6)
+    opts = SolverOptions(**kw)
     probes = [mesh.closest_site((-325, 0)), mesh.closest_site((325, 0))]
     solver = TDGLSolver.from_dimensionless(
         mesh, opts, uniform_field_A(mesh, 0.0), 1.0, U_DEFAULT, GAMMA_DEFAULT, terminal_info=terms,
         current_func={"source": current, "drain": -current}, probe_points=probes,
     )
     ctx = solver.ctx
+    sub = ctx.substructure
+    if mu_solver == "product_default":  # what ships: three levels of nested dissection, the loop may change the solver
+        assert ctx.dense_direct and sub["levels"] == 3 and sub["super_super_blocks"] >= 8
+        assert ctx.direct_switching() == dict(switches=0, paused=False)
+    else:
+        assert sub is None and not ctx.dense_direct
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     solver.update_mu_boundary(0.0)
-    res = ctx.run(60)
+    first = ctx.run(_STRIP_ORACLE_STEPS)
+    got = ctx.get_state()
+    assert (first["pcg_iters"].max() == 0) == (mu_solver == "product_default")
+    if "want" not in _ORACLE_STRIP:
+        o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
+                            adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)
+        _ORACLE_STRIP["want"] = run_time_loop(
+            OracleSolver(mesh, uniform_field_A(mesh, 0.0), 1.0, U_DEFAULT, GAMMA_DEFAULT, o, terminals=terms,
+                         current_func=lambda t: {"source": current, "drain": -current}, probe_points=probes),
+            o, max_steps=_STRIP_ORACLE_STEPS)
+    want = _ORACLE_STRIP["want"]
+    assert max_abs(first["dt"], want["log"].array("dt")) < 1e-9 * first["dt"].max()
+    assert max_abs(np.abs(got["psi"]) ** 2, np.abs(want["psi"]) ** 2) < 1e-9
+    assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-9 * max(1.0, np.abs(want["supercurrent"]).max())
+    assert max_abs(got["normal_current"], want["normal_current"]) < 1e-9 * max(1.0, np.abs(want["normal_current"]).max())
+    assert max_abs(got["mu"], remove_mean(want["mu"])) < 1e-9 * max(1.0, np.abs(remove_mean(want["mu"])).max())
+    more = ctx.run(60 - _STRIP_ORACLE_STEPS)
+    res = {k: np.concatenate([first[k], more[k]]) for k in ("dt", "pcg_iters", "mu", "theta")}
     st = ctx.get_state()
     assert len(res["dt"]) == 60 and res["dt"][-1] > 1e-3  # the controller opened the step up
     assert res["pcg_iters"].max() < 60
