@@ -301,7 +301,10 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
  * synchronisation per step, AMG-PCG); when the running mean of the PCG iterations exceeds 2.5 it comes back, and
  * the next pause has to wait twice as long (256 steps at first, and again after every pause that lasted 1,024 steps or more).  on = 0: off (the direct solve always); on < 0: query
  * only.  *switches / *paused (may be NULL): changes so far, the current state.  The host layer switches it on from
- * 150k sites. */
+ * 150k sites.  The choice is a function of the run's recent history; tdgl_set_state, tdgl_begin_stage, tdgl_set_mu_boundary,
+ * tdgl_set_epsilon and this call with on >= 0 return it to its starting point (direct solve, no windows, the 256-step
+ * wait), so that a restart from a checkpoint takes the same path whatever preceded it.  While the direct solve is paused
+ * mu meets pcg_rtol (the iterative solve's tolerance) instead of the factors' ~1e-14. */
 int tdgl_direct_switching(tdgl_ctx *ctx, int32_t on, int64_t *switches, int32_t *paused);
 int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const int32_t *indptr, const int32_t *indices,
                                            const double *data);
@@ -454,12 +457,16 @@ int tdgl_comm_init_callbacks(tdgl_ctx *ctx, tdgl_halo_fn halo, tdgl_allreduce_fn
  * stores the vector into slot [rank] of every inbox and one that adds the slots in rank order (the same bits on every
  * rank).  Everything runs on the context's one stream: no host synchronisation, no second stream, and work that reads
  * no ghost values is queued between the two launches of an exchange (the overlap is then always on).  Waits are bounded
- * (8 s): a rank that died turns into TDGL_ERR_HIP at the end of tdgl_run, not into a hang.
+ * (tdgl_comm_ipc_set_timeout; 120 s unless that call or TDGL_IPC_TIMEOUT_S says otherwise -- the host layer meets at
+ * a barrier before it queues a batch, so the bound only has to cover what happens inside one): a rank that died turns
+ * into TDGL_ERR_HIP at the end of tdgl_run, not into a hang -- on EVERY rank: the rank whose wait timed out stops
+ * sending and poisons its flags at all peers, whose waits then fail at once instead of consuming stale ghosts.
  * Set-up (after tdgl_set_halo_plan / tdgl_set_deep_halo_plan): every rank calls tdgl_comm_ipc_export (handle64: the
  * 64-byte IPC handle of its inbox; table[4 + 6 world]: where in that inbox each rank's values land), the host layer
  * all-gathers both, every rank calls tdgl_comm_init_ipc with the `world` handles and tables in rank order. */
 int tdgl_comm_ipc_export(tdgl_ctx *ctx, char *handle64, int64_t *table, int64_t table_len);
 int tdgl_comm_init_ipc(tdgl_ctx *ctx, const char *handles, const int64_t *tables);
+int tdgl_comm_ipc_set_timeout(tdgl_ctx *ctx, double seconds);
 /* Overlap of the halo exchanges with the ghost-free rows: the stencil kernels that follow an
  * exchange (psi Laplacian + rhs; level-0 residual of the V-cycle; A p of the CG; edge currents)
  * run their leading ghost-free part on the compute stream while the exchange travels on a second

@@ -737,6 +737,7 @@ extern "C" int tdgl_set_epsilon(tdgl_ctx *ctx, const double *epsilon) {
     if (!epsilon) TDGL_FAIL(ctx, TDGL_ERR_ARG, "tdgl_set_epsilon: null epsilon");
     TDGL_TRY(upload_sites(ctx, epsilon, ctx->eps));
     ctx->have_eps = true;
+    direct_policy_reset(ctx);
     return TDGL_OK;
 }
 
@@ -760,6 +761,7 @@ extern "C" int tdgl_set_mu_boundary(tdgl_ctx *ctx, const double *mu_boundary) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->tab_mu_host.empty() && ctx->nb > 0) ctx->tab_mu_host.assign(mu_boundary, mu_boundary + ctx->nb);
     ctx->tab_mu_dev_synced = !ctx->tab_mu_host.empty();  // (the device holds exactly this array now)
+    direct_policy_reset(ctx);
     return TDGL_OK;
 }
 
@@ -890,6 +892,7 @@ extern "C" int tdgl_set_state(tdgl_ctx *ctx, const double *psi, const double *mu
     ctx->prev_dt = ctx->prev_dt2 = 0.0;  // no mu history: the next solve starts from mu itself
     ctx->g_count = 0;                     // (nor a projection basis)
     ctx->g_row_pending = false;
+    direct_policy_reset(ctx);             // (nor a history for the loop's solver choice)
     return TDGL_OK;
 }
 

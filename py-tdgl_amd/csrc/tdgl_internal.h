@@ -560,3 +560,17 @@ struct tdgl_ctx {
     double prof3_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof3_pending;
 };
+
+// The time loop's solver choice (run.inc: direct_policy) is a function of the run's recent history.  Whatever makes that
+// history meaningless -- a new state, a new stage, new boundary values or a new epsilon handed in by the caller --
+// returns it to its starting point: the direct solve, no windows, the short wait.  So a restart from a checkpoint
+// (tdgl_set_state + tdgl_set_loop_state + tdgl_set_controller_state) takes the same path whatever came before it.
+static inline void direct_policy_reset(tdgl_ctx *ctx) {
+    ctx->direct_paused = false;
+    ctx->direct_switch_steps = 0;
+    ctx->direct_recent_n = 0;
+    ctx->direct_pause_hold = 256;
+    ctx->direct_pcg_ema = 0.0;
+    for (double &w : ctx->direct_win_max) w = 0.0;
+}
+

@@ -246,6 +246,7 @@ SIGNATURES = {
     "tdgl_comm_init_rccl": (C.c_int, [_CTX, C.c_char_p]),
     "tdgl_comm_ipc_export": (C.c_int, [_CTX, C.c_char_p, c_i64p, C.c_int64]),
     "tdgl_comm_init_ipc": (C.c_int, [_CTX, C.c_char_p, c_i64p]),
+    "tdgl_comm_ipc_set_timeout": (C.c_int, [_CTX, C.c_double]),
     "tdgl_comm_test_halo": (C.c_int, [_CTX, c_f64p, C.c_int32, C.c_int32]),
     "tdgl_comm_test_allreduce": (C.c_int, [_CTX, c_f64p, C.c_int64, C.c_int32, C.c_int32]),
     "tdgl_comm_init_callbacks": (C.c_int, [_CTX, HALO_FN, ALLREDUCE_FN, C.c_void_p]),

@@ -205,6 +205,7 @@ class DistributedTDGL:
                 else:
                     payload = pieces[0]
         self.payload = payload
+        self.transport = transport
         self.lp = lp = payload["lp"]
         self.n_global, self.m_global = payload["n_global"], payload["m_global"]
         dev = self.rank if device_id is None else device_id
@@ -301,6 +302,7 @@ class DistributedTDGL:
         (``dict(ok, rank, device, neighbours, checks=[...])``) instead of raising, so that a launcher can print all
         ranks' findings.  (`tdgl_comm_test_halo`, `tdgl_comm_test_allreduce`)"""
         lp, ctx, w = self.lp, self.ctx, self.world
+        self._meet()
         report = dict(rank=self.rank, world=w, neighbours=list(lp.neighbors), n_own=int(lp.n_own), ghosts=int(lp.n_ghost), checks=[])
 
         def f(gid, c=0):  # exactly representable, different for every site and component
@@ -368,8 +370,35 @@ class DistributedTDGL:
         self.ctx.begin_stage()
 
     # -- stepping -----------------------------------------------------------------------------------
-    def run(self, max_steps, end_time=np.inf):
-        res = self.ctx.run(max_steps, end_time)
+    def _meet(self):
+        """Peer-mapped transport: the ranks meet on the host before a batch of kernels is queued.  The in-kernel waits
+        are bounded (`tdgl_comm_ipc_set_timeout`; two minutes unless told otherwise), and nothing else bounds the skew
+        between ranks -- one of them saving a snapshot, a slow file system -- so the host takes it out here."""
+        if self.world > 1 and self.transport == "ipc":
+            self.dist.barrier()
+
+    def run(self, max_steps, end_time=np.inf, host_barrier=True):
+        """``host_barrier=False`` skips the meeting above (tests of the device-side time-out)."""
+        if host_barrier:
+            self._meet()
+        failure = None
+        try:
+            res = self.ctx.run(max_steps, end_time)
+        except RuntimeError as exc:
+            if not (host_barrier and self.world > 1 and self.transport == "ipc"):
+                raise
+            failure = exc
+        if host_barrier and self.world > 1 and self.transport == "ipc":
+            # one rank's failed exchange is every rank's failure: the device side poisons the peers' flags, the host
+            # side agrees on the outcome (a rank that has not looked at its error flag yet must not return a result)
+            import torch
+
+            flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if failure is not None:
+                raise failure
+            if int(flag.item()):
+                raise RuntimeError("tdgl_run failed on another rank (peer-mapped transport): the exchanges of this batch are not to be trusted")
         if self.n_probes and self.world > 1:
             import torch
 

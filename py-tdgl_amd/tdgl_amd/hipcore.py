@@ -638,6 +638,11 @@ class TDGLContext:
         tab = np.ascontiguousarray(np.stack(tables), dtype=np.int64)
         self._chk(self._lib.tdgl_comm_init_ipc(self._ctx, C.c_char_p(blob), tab.ctypes.data_as(_lib.c_i64p)))
 
+    def comm_ipc_set_timeout(self, seconds: float):
+        """Bound of the in-kernel waits of the peer-mapped transport (`tdgl_comm_ipc_set_timeout`; default 120 s, or
+        ``TDGL_IPC_TIMEOUT_S``)."""
+        self._chk(self._lib.tdgl_comm_ipc_set_timeout(self._ctx, float(seconds)))
+
     def comm_test_halo(self, vec, width=1, deep=False):
         """One exchange of ``vec``'s ghost entries through the context's transport (`tdgl_comm_test_halo`)."""
         v = np.ascontiguousarray(vec, dtype=np.float64).copy()

@@ -268,30 +268,44 @@ def _dying_worker(rank, world, port, out_dir):
                               transport="ipc", device_id=0)
         run.set_state(psi0, np.zeros(len(mesh.sites)))
         run.begin_stage()
-        run.run(3)  # both ranks alive: fine
+        # the LAST rank will leave; the first one is patient (60 s), the ones in between are not (8 s)
+        run.ctx.comm_ipc_set_timeout(60.0 if rank == 0 and world > 2 else 8.0)
+        run.run(3)  # all ranks alive: fine
         dist.barrier()
-        if rank == 1:
-            return  # leaves the collective sequence: its partner's next wait can never be satisfied
+        if rank == world - 1:
+            time.sleep(25.0 if world > 2 else 0.0)  # (stays connected to the bootstrap group while the others find out)
+            return  # leaves the collective sequence: its partners' next wait can never be satisfied
         t0 = time.perf_counter()
         try:
-            run.run(3)
+            run.run(3, host_barrier=False)  # (the device side alone: the host meeting would notice a dead process first)
             outcome = "no error"
         except RuntimeError as exc:
             outcome = str(exc)
-        with open(os.path.join(out_dir, "dying.txt"), "w") as f:
+        with open(os.path.join(out_dir, f"dying_{rank}.txt"), "w") as f:
             f.write(f"{time.perf_counter() - t0:.1f}\n{outcome}\n")
     finally:
         dist.destroy_process_group()
 
 
 def test_peer_mapped_transport_turns_a_dead_rank_into_an_error_not_a_hang(tmp_path):
-    """Waits of the peer-mapped transport are bounded (8 s): when a rank leaves, its neighbour's next exchange times
+    """Waits of the peer-mapped transport are bounded (8 s here): when a rank leaves, its neighbour's next exchange times
     out ONCE, every later wait of that context returns at once, and `run` raises at its end -- the box is never left
     with a kernel that spins for good."""
     mp.spawn(_dying_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    seconds, outcome = open(os.path.join(tmp_path, "dying.txt")).read().split("\n")[:2]
+    seconds, outcome = open(os.path.join(tmp_path, "dying_0.txt")).read().split("\n")[:2]
     assert "did not arrive within 8 s" in outcome
     assert 7.0 < float(seconds) < 20.0
+
+
+def test_a_timed_out_rank_poisons_its_peers_instead_of_feeding_them_stale_ghosts(tmp_path):
+    """Three ranks; rank 2 leaves.  Rank 1 waits 8 s, gives up, stops sending and stores the poison value into every
+    flag it owns at its peers; rank 0 -- whose own bound is a minute -- fails WITH it, within seconds, instead of either
+    waiting out its minute or (round 5) carrying on with whatever its inbox held and returning TDGL_OK."""
+    mp.spawn(_dying_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    for rank, bound in ((1, "8 s"), (0, "60 s")):
+        seconds, outcome = open(os.path.join(tmp_path, f"dying_{rank}.txt")).read().split("\n")[:2]
+        assert f"did not arrive within {bound}" in outcome, (rank, outcome)
+        assert 7.0 < float(seconds) < 22.0, (rank, seconds)
 
 
 def _soak_worker(rank, world, port, transport, out_dir, steps):

@@ -225,8 +225,62 @@ def test_config3_1m_sites_linearity_and_idempotence_of_operators():
     ctx.close()
 
 
-@pytest.mark.parametrize("side,n_sites,steps", [(930, 1000431, 30), (1860, 3998502, 8)])
-def test_config3_and_5_steps_satisfy_their_defining_equations(side, n_sites, steps):
+_ORACLE_700K = {}
+
+
+@pytest.mark.parametrize("precond", ["factors", "vcycle", "by_predicted_cost"])
+def test_700k_film_first_steps_match_oracle_with_either_preconditioner(precond, direct_solve, monkeypatch):
+    """Between 0.65 and 1.3 million sites (BASELINE config 3's regime) the product's mu solve is a CG with TWO resident
+    preconditioners -- the AMG V-cycle and the three-level nested-dissection factors stored in fp32
+    (`tdgl_poisson_set_substructure_precond`) -- and takes the cheaper one per solve.  704k sites, b = 0.1, 12 steps from
+    psi = 1 against the oracle (SuperLU, one factorisation for the three cases) with each branch forced and with the
+    choice left to the library: dt, |psi|^2, mu - <mu>, J_s, J_n at 1e-9."""
+    from types import SimpleNamespace
+
+    from oracle import OracleSolver, run_time_loop
+    from tdgl_amd import SolverOptions, TDGLSolver
+    from tdgl_amd.hipcore import TDGLContext
+
+    monkeypatch.setattr(TDGLContext, "PD_CHOICE", dict(factors=1, vcycle=2, by_predicted_cost=0)[precond])
+    monkeypatch.setattr(TDGLContext, "AMG_CANDIDATES", 1)  # (set-up time: one hierarchy)
+    mesh = synthetic_mesh(780)
+    n = len(mesh.sites)
+    assert TDGLContext.SUB2_MAX_SITES < n < TDGLContext.PD_MAX_SITES
+    A = uniform_field_A(mesh, 0.1)
+    kw = dict(solve_time=1e9, dt_init=1e-3, save_every=10**6)
+    solver = TDGLSolver.from_dimensionless(mesh, SolverOptions(**kw, pcg_rtol=1e-11), A, 1.0, U_DEFAULT, GAMMA_DEFAULT)
+    ctx = solver.ctx
+    pd = ctx.precond_direct
+    assert pd and pd["levels"] == 3 and pd["storage"] == "fp32" and pd["check_iterations"] <= 3 and not ctx.dense_direct
+    assert ctx.substructure is None  # (the context's site order is the reverse Cuthill-McKee one: 16-bit column offsets in K1)
+    ctx.set_state(solver.psi_init, solver.mu_init)
+    ctx.begin_stage()
+    res = ctx.run(12)
+    got = ctx.get_state()
+    st = ctx.precond_direct_stats()
+    ctx.close()
+    assert st["solves_factors"] + st["solves_vcycle"] == 12
+    if precond == "factors":
+        assert st["solves_vcycle"] == 0 and st["iterations_factors"] <= 24 and res["pcg_iters"].max() <= 2
+    elif precond == "vcycle":
+        assert st["solves_factors"] == 0 and res["pcg_iters"].max() > 3
+    else:  # from psi = 1 the first right-hand sides are unlike each other: the factors are the cheaper solve
+        assert st["solves_factors"] >= 6
+    if "want" not in _ORACLE_700K:
+        o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
+                            adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)
+        _ORACLE_700K["want"] = run_time_loop(OracleSolver(mesh, A, 1.0, U_DEFAULT, GAMMA_DEFAULT, o), o, max_steps=12)
+    want = _ORACLE_700K["want"]
+    assert max_abs(res["dt"], want["log"].array("dt")) < 1e-9 * res["dt"].max()
+    assert max_abs(np.abs(got["psi"]) ** 2, np.abs(want["psi"]) ** 2) < 1e-9
+    assert max_abs(got["supercurrent"], want["supercurrent"]) < 1e-9
+    assert max_abs(got["normal_current"], want["normal_current"]) < 1e-9
+    assert max_abs(got["mu"], remove_mean(want["mu"])) < 1e-9 * max(1.0, np.abs(remove_mean(want["mu"])).max())
+
+
+@pytest.mark.parametrize("side,n_sites,steps,mu_solver", [(930, 1000431, 30, "amg_pcg"), (930, 1000431, 30, "product_default"),
+                                                          (1860, 3998502, 8, "amg_pcg")])
+def test_config3_and_5_steps_satisfy_their_defining_equations(side, n_sites, steps, mu_solver, request):
     """BASELINE configs 3 (1M sites, the headline) and 5 (4M sites): the oracle's LU cannot be run at
     these sizes inside a test, so the stepped state is checked through the equations that define
     it, with the oracle's operator matrices: L mu = div J_s (solver.py:507-516), J_n = -grad mu
@@ -234,11 +288,14 @@ def test_config3_and_5_steps_satisfy_their_defining_equations(side, n_sites, ste
     from oracle.fv_operators import divergence_matrix, gradient_matrix, laplacian_matrix
     from tdgl_amd import SolverOptions, TDGLSolver
 
+    if mu_solver == "product_default":  # (config 3 as it ships: the fp32 factors next to the V-cycle, chosen per solve)
+        request.getfixturevalue("direct_solve")
     mesh = synthetic_mesh(side)
     assert len(mesh.sites) == n_sites
     opts = SolverOptions(solve_time=1e9, dt_init=1e-4, dt_max=1e-1, save_every=10**9, pcg_rtol=1e-11)
     solver = TDGLSolver.from_dimensionless(mesh, opts, uniform_field_A(mesh, 0.1), 1.0, U_DEFAULT, GAMMA_DEFAULT)
     ctx = solver.ctx
+    assert (ctx.precond_direct is not None) == (mu_solver == "product_default")
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     res = ctx.run(steps)
