@@ -264,8 +264,8 @@ def test_700k_film_first_steps_match_oracle_with_either_preconditioner(precond, 
         assert st["solves_vcycle"] == 0 and st["iterations_factors"] <= 24 and res["pcg_iters"].max() <= 2
     elif precond == "vcycle":
         assert st["solves_factors"] == 0 and res["pcg_iters"].max() > 3
-    else:  # from psi = 1 the first right-hand sides are unlike each other: the factors are the cheaper solve
-        assert st["solves_factors"] >= 6
+    else:  # from psi = 1 the first right-hand sides are unlike each other: the factors are the cheaper solve for some of them
+        assert st["solves_factors"] >= 3 and st["solves_vcycle"] >= 1
     if "want" not in _ORACLE_700K:
         o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
                             adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)
