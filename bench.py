@@ -955,7 +955,11 @@ def main():
                      + (f"mu solve: {r.setup['mu_solver']}" if r.setup.get("mu_solver", "amg_pcg") != "amg_pcg" else
                         f"PCG rtol {args.rtol:g} ({args.smoother} AMG smoother, degree {args.nu_fine} on level 0 / {args.nu} below"
                         + ("" if args.precond_fp64 else "; V-cycle operators stored in fp32"
-                           + ("" if args.precond_fp32 else " (level 0: binary16)") + ", all arithmetic and the CG in fp64") + ")")
+                           + ("" if args.precond_fp32 else " (level 0: binary16)") + ", all arithmetic and the CG in fp64") + ")"
+                        + ("" if not r.setup.get("precond_direct") else
+                           "; second resident preconditioner: three levels of nested dissection with explicit factors stored in fp32, "
+                           + {"auto": "the cheaper of the two per solve by predicted cost", "factors": "forced for every solve",
+                              "vcycle": "never used (forced off)"}[args.mu_precond]))
                      + f", J_s/J_n formed every step; steady state: {args.preroll} pre-roll + {args.warmup} warm-up steps "
                        f"untimed, then {args.steps} timed steps at {main_line['pcg']['mean_iterations']} PCG iterations per step",
             sites=r.n, edges=r.m, amg_levels=r.sizes, preroll=args.preroll,

@@ -208,7 +208,13 @@ class TDGLContext:
     # sites 3.0k against 2.0k steps/s, 450k 2.3k against 1.9k in an evolving vortex state; the 500k-site strip with terminals
     # in its STATIONARY state (an exact guess, 1.5 iterations) 1.8k against 3.8k -- which the time loop notices by itself
     # (`tdgl_direct_switching`); with three levels from 350k sites on: 600k sites 2.06k against 1.58k.
-    SUB2_MAX_SITES = 650_000
+    # (round 6: from 400k sites the same factors in fp32 PRECONDITION the CG instead, `PD_MAX_SITES` below -- same-box
+    # steps/s, direct solve / two-preconditioner CG, headline | vortex | 3,000-step stretch | late windows: 350k-site film 3,270 flat /
+    # 2,912 | 2,777 | 3,554 | 4,655; 450k 2,620 flat / 2,647 | 2,712 | 3,378 | 2,655; 600k 2,068 flat / 2,137 | 2,231 | 2,607 |
+    # 2,164; 501k-site strip 2,372 -> 4,714 once the loop has paused the direct solve / 3,655 -> 4,955 with no pause to wait
+    # for and the context in reverse Cuthill-McKee order; 250k-site film 4,208 / 3,195: there the iterative step is
+    # launch-bound and the direct solve in the run-ahead loop stays)
+    SUB2_MAX_SITES = 400_000
     # from here on the separator right-hand sides of the way down come from the sparse coupling blocks (two more
     # launches, no -E^T rows: `tdgl_poisson_set_substructure_coupling`)
     # (measured: 60k sites 13.0k against 13.6k steps/s, 120k 7.5k / 8.1k, 160k 5.9k / 6.2k, 250k 4.1k / 3.9k)
@@ -228,8 +234,10 @@ class TDGLContext:
     SUB2_SUPER = 0
     # above SUB2_MAX_SITES and up to here the three-level factors are built as well, stored in fp32, and PRECONDITION the
     # CG (`tdgl_poisson_set_substructure_precond`): at 1M sites the fp64 factors are 2.9 GB per solve -- 700 us, what
-    # 7-8 AMG-preconditioned iterations cost --, in fp32 half of that buys five decades per application, i.e. ONE CG
-    # iteration from the projection guess.  Per solve the library takes the V-cycle or the factors by predicted cost.
+    # 7-8 AMG-preconditioned iterations cost --, in fp32 half of that buys 6.5 decades per application, i.e. ONE CG
+    # iteration from the projection guess.  Per solve the library takes the V-cycle or the factors by predicted cost:
+    # no state, no hysteresis -- a stationary strip runs on the V-cycle from its first step, a film in flux flow on the
+    # factors, and the context keeps the reverse Cuthill-McKee order (16-bit column offsets in the stencil kernels).
     PD_MAX_SITES = int(__import__("os").environ.get("TDGL_PD_MAX_SITES", "1300000"))
     PD_CHOICE = 0  # 0: by predicted cost, 1: always the factors, 2: never (tests / A-B runs)
 

@@ -116,7 +116,7 @@ def three_level_solve(two_level_solve, monkeypatch):
 def precond_direct_solve(three_level_solve, monkeypatch):
     """Every mesh from 200 sites up carries the three-level factors as the CG's PRECONDITIONER (fp32 storage, the
     context in reverse Cuthill-McKee order: `tdgl_poisson_set_substructure_precond`), which the product does between
-    `SUB2_MAX_SITES` and `PD_MAX_SITES` (0.65 - 1.3 million sites) -- and every solve uses them (`PD_CHOICE` 1; the
+    `SUB2_MAX_SITES` and `PD_MAX_SITES` (0.4 - 1.3 million sites) -- and every solve uses them (`PD_CHOICE` 1; the
     product lets the library choose per solve)."""
     from tdgl_amd.hipcore import TDGLContext
 

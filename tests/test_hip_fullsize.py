@@ -69,8 +69,8 @@ _STRIP_ORACLE_STEPS = 16
 @pytest.mark.parametrize("mu_solver", ["amg_pcg", "product_default"])
 def test_config4_strip_500k_current_conservation_and_poisson_residual(mu_solver, request):
     """BASELINE config 4: strip with two current terminals, ~500k sites, mu Poisson every step -- with the iterative mu
-    solve and with what the product ships at this size (`product_default`: the three-level direct solve in the
-    run-ahead loop, with the loop's solver choice switched on).  Both: 16 steps against the oracle (SuperLU; terminals
+    solve and with what the product ships at this size (`product_default`: CG preconditioned per solve by the AMG
+    V-cycle or by the fp32-stored three-level nested-dissection factors, whichever is predicted to be cheaper).  Both: 16 steps against the oracle (SuperLU; terminals
     and `mu_boundary`, solver.py:325-345, 489-520) at 1e-9 in dt, |psi|^2, mu - <mu>, J_s, J_n; then on to step 60 for
     the size-independent checks."""
     from types import SimpleNamespace
@@ -95,17 +95,21 @@ def test_config4_strip_500k_current_conservation_and_poisson_residual(mu_solver,
     )
     ctx = solver.ctx
     sub = ctx.substructure
-    if mu_solver == "product_default":  # what ships: three levels of nested dissection, the loop may change the solver
-        assert ctx.dense_direct and sub["levels"] == 3 and sub["super_super_blocks"] >= 8
-        assert ctx.direct_switching() == dict(switches=0, paused=False)
+    pd = ctx.precond_direct
+    if mu_solver == "product_default":
+        # what ships at 501k sites: CG with two resident preconditioners -- the AMG V-cycle and three levels of nested
+        # dissection stored in fp32 --, the cheaper one per solve; the context in reverse Cuthill-McKee order
+        assert pd and pd["levels"] == 3 and pd["storage"] == "fp32" and pd["super_super_blocks"] >= 8 and sub is None and not ctx.dense_direct
     else:
-        assert sub is None and not ctx.dense_direct
+        assert sub is None and pd is None and not ctx.dense_direct
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     solver.update_mu_boundary(0.0)
     first = ctx.run(_STRIP_ORACLE_STEPS)
     got = ctx.get_state()
-    assert (first["pcg_iters"].max() == 0) == (mu_solver == "product_default")
+    if mu_solver == "product_default":  # (both preconditioners get their turn in the first steps of a relaxing strip)
+        st_pd = ctx.precond_direct_stats()
+        assert st_pd["solves_factors"] + st_pd["solves_vcycle"] == _STRIP_ORACLE_STEPS and st_pd["solves_factors"] >= 1
     if "want" not in _ORACLE_STRIP:
         o = SimpleNamespace(skip_time=0.0, dt_max=0.1, adaptive=True, adaptive_window=10, max_solve_retries=10,
                             adaptive_time_step_multiplier=0.25, terminal_psi=0.0, **kw)

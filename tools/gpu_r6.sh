@@ -44,6 +44,25 @@ prof)
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB "rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline --vortex-window off $PA" "round 6 ($TAG); MI355X, ROCm 7.2" > $OUT/${TAG}_kernel_stats_${PN}.txt && head -40 $OUT/${TAG}_kernel_stats_${PN}.txt | cut -c1-220
   rm -rf $OUT/prof_${TAG}/*.db 2>/dev/null
   ;;
+pdmid)
+  # mid sizes: the product default (fp64 direct solve in the run-ahead loop + the loop's solver choice) against the
+  # two-preconditioner CG (fp32 factors / V-cycle per solve) forced down to 100k sites
+  for W in ${PD_WORKLOADS:-250k 450k strip250k strip500k}; do
+    for V in default pd; do
+      EXTRA=""; [ $V = pd ] && EXTRA="--sub-limits 32000,100000"
+      timeout 900 python bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --late-steps 3000 $EXTRA > $OUT/BENCH_${TAG}_${W}_$V.json 2> $OUT/${TAG}_${W}_$V.err
+      python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/BENCH_${TAG}_${W}_$V.json"))
+    pr=lambda x: (x.get("value"), (x.get("pcg") or {}).get("mean_iterations"), (x.get("preconditioner") or x.get("pcg",{}).get("preconditioner") or {}).get("solves_factors"), x.get("direct_switching") or x.get("pcg",{}).get("direct_switching"))
+    print("$W $V", "headline", pr(d), "| vortex", pr(d.get("vortex_window") or {}), "| sustained", (d.get("sustained") or {}).get("value"), "| late", pr(d.get("late_window") or {}), "| setup", d["setup_s"]["total"])
+except Exception as e:
+    print("$W $V no line", e); print(open("$OUT/${TAG}_${W}_$V.err").read()[-800:])
+PY
+    done
+  done
+  ;;
 *) echo "unknown stage $STAGE";;
 esac
 done

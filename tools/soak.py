@@ -37,5 +37,6 @@ while done < total:
                           psi_retries=st["psi_retries"], fp64_fallbacks=ps["fp64_fallbacks"], finite=bool(np.all(np.isfinite(a2))),
                           max_abs_sq_psi=float(a2.max()), sites_below_0p1=int((a2 < 0.1).sum()),
                           probes_finite=None if res["mu"] is None else bool(np.all(np.isfinite(res["mu"]))),
-                          direct=ctx.direct_stats() if ctx.dense_direct else None)), flush=True)
+                          direct=ctx.direct_stats() if ctx.dense_direct else None,
+                          preconditioner=ctx.precond_direct_stats() if getattr(ctx, "precond_direct", None) else None)), flush=True)
     assert np.all(np.isfinite(a2)) and a2.max() < 1.5  # (|psi|^2 overshoots 1 by a few 1e-3 when dt sits at dt_max: the scheme, not an error)
