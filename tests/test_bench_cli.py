@@ -43,6 +43,22 @@ def test_two_ranks_sharing_the_gpu_race_the_transports_and_report_it():
     assert d["conservation"]["relative"] < 1e-7 and d["conservation"]["max_abs_current"] > 1e-3
 
 
+def test_eight_ranks_sharing_the_gpu_run_the_drivers_command_shape():
+    """The driver's multi-GPU command with the rank count of the scaling run (`--gpus 8`), rehearsed on the one GPU there
+    is: the peer-mapped transport passes its self-test on all eight ranks, RCCL's refusal of ranks that share a device is
+    RECORDED in `transport.selftest` (not discovered on the 8-GPU box), the decomposed path is followed by the oracle,
+    and the final state conserves current across all seven cuts.  (The full-size rehearsal -- 1M sites cut 8 ways with
+    config 5 attached, 233 s of wall time -- is profiles/BENCH_r08c_1M_8ranks_sharing_one_gpu_DRY_RUN.json.)"""
+    d = _run("--gpus", "8", "--share-devices", "--workload", "60k", "--steps", "10", "--warmup", "5", "--preroll", "45",
+             "--config5", "off", timeout=900)
+    assert d["n_gpus"] == 8 and d["value"] > 0 and "DRY RUN" in d["config"]["parallelism"]
+    by = {t["transport"]: t for t in d["transport"]["selftest"]}
+    assert d["transport"]["used"] == "ipc" and by["ipc"]["ok"] and by["ipc"]["checks_per_rank"] >= 5
+    assert not by["rccl"]["ok"] and len(by["rccl"]["failures"]) == 8 and all("RCCL" in f["error"] for f in by["rccl"]["failures"])
+    assert d["parity_vs_oracle"]["ok"] and "8 rank(s)" in d["parity_vs_oracle"]["source"]
+    assert d["conservation"]["relative"] < 1e-7
+
+
 def test_decomposed_run_is_followed_by_the_oracle_from_the_same_state():
     """With the CPU leg on, a decomposed run's K timed steps are taken by the oracle too, from the state assembled from
     both ranks before the clock started: `parity_vs_oracle` of the decomposed path (no `cpu_baseline`: that is a
