@@ -208,3 +208,43 @@ def pcg_deep(dp, lp, h, plan, b_own, x0_loc=None, rtol=1e-10, maxiter=200):
     halo_exchange(lp, x)
     counts["thin_exchanges"] += 1
     return x, it, counts
+
+
+# ---------------------------------------------------------------- rank-level nested dissection (tdgl_amd/schur_dd.py)
+def schur_setup_dist(lp, piece):
+    """What `DistributedTDGL` does at set-up, with SciPy's LU standing in for the rank's local factors: the interface
+    complement ``S = A_GG - sum_r A_GI_r A_II_r^-1 A_I_rG`` summed over the ranks (ONE sum of |Gamma|^2 values), its
+    pseudo-inverse on every rank."""
+    import scipy.sparse.linalg as spla
+
+    from tdgl_amd.schur_dd import interface_pinv
+
+    lu = spla.splu(piece.A_II.tocsc())
+    touched = np.unique(piece.A_IG.indices)
+    X = lu.solve(piece.A_IG[:, touched].toarray())
+    S = piece.A_GG_owned.toarray()
+    S[np.ix_(touched, touched)] -= piece.A_GI[touched] @ X
+    t = torch.from_numpy(S)
+    dist.all_reduce(t)
+    return lu, interface_pinv(t.numpy())
+
+
+def schur_apply_dist(lp, piece, lu, Spinv, r_own, counts=None):
+    """One application ``z = M r`` on the owned rows: two local solves, ONE all-reduce of |Gamma| doubles, a replicated
+    dense product (the sequence of csrc/poisson.inc: precond_schur_apply)."""
+    r_loc = np.zeros(lp.n_loc)
+    r_loc[: lp.n_own] = r_own
+    y = lu.solve(r_loc[piece.interior])
+    t = np.zeros(piece.n_gamma)
+    t[piece.gamma_owned_gid] = r_loc[piece.gamma_owned_local]
+    t -= piece.A_GI @ y
+    t = allreduce_sum(t)
+    if counts is not None:
+        counts["allreduces"] = counts.get("allreduces", 0) + 1
+        counts["allreduce_values"] = counts.get("allreduce_values", 0) + piece.n_gamma
+    xg = Spinv @ t
+    xi = y - lu.solve(piece.A_IG @ xg)
+    z = np.zeros(lp.n_own)
+    z[piece.interior] = xi  # (interior ids are owned ids: < n_own)
+    z[piece.gamma_owned_local] = xg[piece.gamma_owned_gid]
+    return z
