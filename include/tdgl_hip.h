@@ -329,6 +329,39 @@ int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const i
 int tdgl_poisson_set_substructure_precond(tdgl_ctx *ctx, const int32_t *site_map, int32_t fp32_storage, double *t_apply_us,
                                           double *t_vcycle_us);
 int tdgl_poisson_precond_choice(tdgl_ctx *ctx, int32_t mode);
+/* The same preconditioner in one-process-per-GPU mode: RANK-LEVEL nested dissection (csrc/schur.inc; host side
+ * tdgl_amd/schur_dd.py).  Gamma = a vertex cover of the edges between ranks (n_gamma sites, one global numbering);
+ * every rank describes the factors of ITS interior block A_II -- its owned sites outside Gamma, in a local dissection
+ * order; positive definite, so the last level's Schur complement gets a plain inverse and no gauge is carried --
+ * between tdgl_poisson_schur_begin and tdgl_poisson_schur_finish with the calls of the single-GPU solve
+ * (tdgl_poisson_set_substructure / _inner / _coupling on a vector of n_interior entries).
+ *   tdgl_poisson_schur_complement: out[n_gamma, n_gamma] = A_GI A_II^-1 A_IG, formed column by column with the resident
+ *     fp64 factors; the host layer sums S = A_GG - (these) over the ranks -- the ONLY communication of the set-up;
+ *   tdgl_poisson_schur_finish: S (the same on every rank) is pseudo-inverted on the device, the factors are stored in
+ *     fp32 (fp32_storage != 0), both preconditioners are timed (collectively: every rank calls it at the same point);
+ *   tdgl_poisson_set_precond_times: the host layer hands every rank the SAME pair of times (the maximum over ranks), so
+ *     that the per-solve choice of pcg_solve is the same everywhere.
+ * One application: y_I = A_II^-1 r_I, t = r_G - sum_r A_GI y_I (ONE all-reduce of n_gamma doubles), x_G = S^+ t
+ * (replicated), x_I = y_I - A_II^-1 A_IG x_G: with exact factors a direct solve (what the reference's LU is,
+ * tdgl/solver/solver.py:516), with fp32 storage ~6 decades per application -- per step one such sum, one exchange of
+ * z's ghost layer and the CG's one sum of 3 x 1024 partials, instead of ~9 AMG-preconditioned iterations of three
+ * collectives each. */
+typedef struct {
+    int64_t n_interior;               /* owned sites outside Gamma */
+    int64_t n_gamma;                  /* |Gamma|, the same on every rank */
+    int64_t n_gamma_owned;
+    const int32_t *interior;          /* [n_interior] local (owned) site at local dissection position i */
+    const int32_t *gamma_owned_local; /* [n_gamma_owned] local site ... */
+    const int32_t *gamma_owned_gid;   /* ... and its position in Gamma */
+    const int32_t *gi_indptr, *gi_indices; /* A_GI [n_gamma x n_interior] CSR (columns: local dissection positions) */
+    const double *gi_data;
+    const int32_t *ig_indptr, *ig_indices; /* A_IG [n_interior x n_gamma] CSR */
+    const double *ig_data;
+} tdgl_schur_piece;
+int tdgl_poisson_schur_begin(tdgl_ctx *ctx, const tdgl_schur_piece *piece);
+int tdgl_poisson_schur_complement(tdgl_ctx *ctx, double *out);
+int tdgl_poisson_schur_finish(tdgl_ctx *ctx, const double *S, int32_t fp32_storage, double *t_apply_us, double *t_vcycle_us);
+int tdgl_poisson_set_precond_times(tdgl_ctx *ctx, double t_apply_us, double t_vcycle_us);
 int tdgl_get_precond_direct_stats(tdgl_ctx *ctx, int64_t *out4, double *out3, int32_t reset);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is

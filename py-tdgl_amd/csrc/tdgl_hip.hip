@@ -602,6 +602,7 @@ static inline int64_t now_ns() {
 #include "comm.inc"
 #include "poisson.inc"
 #include "dense.inc"
+#include "schur.inc"
 #include "screening.inc"
 #include "run.inc"
 

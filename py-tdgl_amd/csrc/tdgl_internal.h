@@ -409,6 +409,23 @@ struct tdgl_ctx {
     double pd_t_apply_us = 0.0, pd_t_vcycle_us = 0.0;  // measured at set-up: one application of either preconditioner
     int64_t pd_solves = 0, pd_iters = 0, pd_amg_solves = 0, pd_amg_iters = 0;  // solves / iterations by preconditioner since the last reset
     bool pd_last = false;                 // the last solve used the factors
+    // Rank-level nested dissection (one process per GPU; schur.inc, tdgl_poisson_schur_begin / _complement / _finish): the
+    // resident factors are those of THIS RANK'S INTERIOR block A_II (sub_n_local sites in the local dissection order, positive
+    // definite: plain inverse of the top separator, no gauge), Gamma = the interface between the ranks (schur_ng sites,
+    // global numbering), schurS32 = pinv of the interface complement in symmetric fp32 tiles on every rank.  One
+    // application = two local solves + ONE all-reduce of schur_ng doubles + a replicated dense product.
+    int64_t sub_n_local = 0;               // > 0: length of the vector the first level works on (instead of n)
+    bool sub_nonsingular = false;
+    bool schur_pending = false, schur_on = false;
+    int64_t schur_ng = 0, schur_ngo = 0;
+    tdgl::DevBuf<int32_t> schur_owner_local;   // [ng] local index of the Gamma site if this rank owns it, else -1
+    tdgl::DevBuf<int32_t> schur_go_local, schur_go_gid;  // [ngo] owned Gamma sites: local index, position in Gamma
+    tdgl::Csr schur_GI, schur_IG;          // A_GI [ng x n_I], A_IG [n_I x ng] (columns / rows in the local dissection order)
+    tdgl::DevBuf<double> schurS64;         // tiles of the pseudo-inverse (fp64 until the conversion)
+    tdgl::DevBuf<float> schurS32;
+    tdgl::DevBuf<double> schur_part;
+    int schur_tiles = 0;
+    tdgl::DevBuf<double> schur_t, schur_rg, schur_xg, schur_y, schur_v, schur_c;  // [ng] x 3, [n_I] x 3
     bool sub_need_coupling[3] = {false, false, false};  // a level was described without its -E^T rows and its coupling block is not there yet
     // Solver choice in the time loop (tdgl_direct_switching; meshes where BOTH a direct solve and the hierarchy are
     // resident and large enough for the choice to matter).  A direct solve costs the same whatever the state; AMG-PCG

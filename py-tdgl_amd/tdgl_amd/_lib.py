@@ -167,6 +167,25 @@ class Substructure(C.Structure):
     ]
 
 
+class SchurPiece(C.Structure):
+    """`tdgl_schur_piece` (include/tdgl_hip.h): one rank's share of the rank-level dissection."""
+
+    _fields_ = [
+        ("n_interior", C.c_int64),
+        ("n_gamma", C.c_int64),
+        ("n_gamma_owned", C.c_int64),
+        ("interior", c_i32p),
+        ("gamma_owned_local", c_i32p),
+        ("gamma_owned_gid", c_i32p),
+        ("gi_indptr", c_i32p),
+        ("gi_indices", c_i32p),
+        ("gi_data", c_f64p),
+        ("ig_indptr", c_i32p),
+        ("ig_indices", c_i32p),
+        ("ig_data", c_f64p),
+    ]
+
+
 class SubstructurePlan(C.Structure):
     _fields_ = [
         ("n_interior", C.c_int64),
@@ -238,6 +257,10 @@ SIGNATURES = {
     "tdgl_poisson_set_substructure_coupling": (C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p]),
     "tdgl_poisson_set_substructure_precond": (C.c_int, [_CTX, c_i32p, C.c_int32, c_f64p, c_f64p]),
     "tdgl_poisson_precond_choice": (C.c_int, [_CTX, C.c_int32]),
+    "tdgl_poisson_schur_begin": (C.c_int, [_CTX, C.POINTER(SchurPiece)]),
+    "tdgl_poisson_schur_complement": (C.c_int, [_CTX, c_f64p]),
+    "tdgl_poisson_schur_finish": (C.c_int, [_CTX, c_f64p, C.c_int32, c_f64p, c_f64p]),
+    "tdgl_poisson_set_precond_times": (C.c_int, [_CTX, C.c_double, C.c_double]),
     "tdgl_get_precond_direct_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p, C.c_int32]),
     "tdgl_poisson_build_substructure": (C.c_int, [_CTX, C.POINTER(SubstructurePlan), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),

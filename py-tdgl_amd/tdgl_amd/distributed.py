@@ -78,7 +78,8 @@ def prepare_payloads(mesh, world, link_exponents, epsilon=1.0, **kw):
 
 
 def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, terminal_info=(), mu_boundary=None,
-                         probe_points=None, screening=None, max_coarse=None, hierarchy=None, deep="auto", plan_kw=None):
+                         probe_points=None, screening=None, max_coarse=None, hierarchy=None, deep="auto", plan_kw=None,
+                         schur=True):
     """Everything the ranks of a `world`-way run need, computed ONCE (by the root rank or ahead of
     time): the partition, each rank's sub-mesh + halo plan, its slice of AMG level 0 and of the
     inputs, and the coarse levels (replicated, one shared object).  Returns a list of `world`
@@ -126,6 +127,14 @@ def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, ter
     eps = np.asarray(epsilon, dtype=float) * np.ones(n)
     mu_b = np.zeros(len(em.boundary_edge_indices)) if mu_boundary is None else np.asarray(mu_boundary, dtype=float)
     probes = None if probe_points is None else np.asarray(probe_points, dtype=np.int64)
+    # rank-level nested dissection (schur_dd.py): the interface between the ranks and its numbering, once for the job
+    is_gamma = gamma_gid = None
+    n_gamma = 0
+    if schur and int(world) > 1:
+        from .schur_dd import gamma_numbering, interface_cover
+
+        is_gamma = interface_cover(em.edges, part)
+        gamma_gid, n_gamma = gamma_numbering(is_gamma)
     out = []
     deep_plans = {}
     if use_deep:  # send lists come from the OTHER ranks' receive lists: all pieces are cut together
@@ -141,6 +150,8 @@ def prepare_payloads_for(mesh, world, ranks, link_exponents, epsilon=1.0, *, ter
             coarse=coarse, link_exponents=A_e[lp.edge_local_to_global], epsilon=eps[l2g],
             mu_boundary=mu_b[lp.boundary_positions], n_probes=0 if probes is None else len(probes),
         )
+        if is_gamma is not None and n_gamma >= 2:
+            pay["schur"] = dict(is_gamma=is_gamma[l2g], gid=gamma_gid[l2g], n_gamma=int(n_gamma))
         if probes is not None:
             g2l = np.full(n, -1, dtype=np.int64)
             g2l[l2g[: lp.n_own]] = np.arange(lp.n_own)
@@ -178,7 +189,8 @@ class DistributedTDGL:
 
     def __init__(self, mesh, options, link_exponents=None, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
                  terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
-                 overlap="auto", screening=None, root=None, payload=None, max_coarse=None, deep="auto", plan_kw=None):
+                 overlap="auto", screening=None, root=None, payload=None, max_coarse=None, deep="auto", plan_kw=None,
+                 schur="auto", schur_blocks=None, schur_choice=None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -267,6 +279,32 @@ class DistributedTDGL:
         if self.n_probes:
             self._probe_mine = payload["probe_mine"]
             ctx.set_probes(payload["probe_local"])
+        # the CG's second preconditioner: rank-level nested dissection (schur_dd.py; one all-reduce of |Gamma| doubles
+        # per application where the distributed AMG cycle needs an exchange and two sums per iteration)
+        self.schur = None
+        sp = payload.get("schur")
+        want = sp is not None and self.world > 1 and self.screening is None and (
+            schur is True or (schur == "auto" and self.SCHUR_MIN_SITES <= self.n_global and lp.n_own <= TDGLContext.PD_MAX_SITES
+                              and sp["n_gamma"] <= self.SCHUR_MAX_INTERFACE))
+        if want:
+            import torch
+
+            from .schur_dd import build_piece
+
+            def reducer(op):
+                def f(a):
+                    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+                    dist.all_reduce(t, op=op)
+                    return t.numpy()
+                return f
+
+            piece = build_piece(lp, sp["is_gamma"], sp["gid"], sp["n_gamma"], blocks=schur_blocks)
+            if ctx.build_schur_precond(piece, reducer(dist.ReduceOp.SUM), reducer(dist.ReduceOp.MAX), choice=schur_choice):
+                self.schur = ctx.precond_direct
+
+    # meshes from here on get the rank-level dissection by default (`schur="auto"`), interfaces up to this many sites
+    SCHUR_MIN_SITES = 100_000
+    SCHUR_MAX_INTERFACE = 16_000
 
     # -- gloo transport (tests) -----------------------------------------------------------------
     def _halo_cb(self, send, send_off, recv, recv_off, ranks):

@@ -518,6 +518,68 @@ class TDGLContext:
         self.precond_direct_stats(reset=True)
         return True
 
+    def build_schur_precond(self, piece, allreduce_sum, allreduce_max, choice=None) -> bool:
+        """One-process-per-GPU mode: this rank's share of the RANK-LEVEL nested dissection (`schur_dd.SchurPiece`) as the
+        CG's second preconditioner (`tdgl_poisson_schur_begin` ... `_finish`).  ``allreduce_sum(array) -> array`` /
+        ``allreduce_max(array) -> array`` over the bootstrap group: the interface complement is summed ONCE, the measured
+        times of the two preconditioners are agreed on (so that every rank takes the same choice in every solve).  Every
+        rank calls this at the same point; returns whether the preconditioner is on (the same answer on every rank)."""
+        from .substructure import build_substructure_levels, pack_for_device
+
+        ok = 1.0
+        levels = packed = None
+        with _Stopwatch(self.setup_times, "substructure_host"):
+            try:
+                levels = build_substructure_levels(piece.A_II, piece.ptrs, gauge=False)
+                packed = [pack_for_device(lv, True) for lv in levels]
+            except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
+                self.setup_times["substructure_error"] = repr(exc)
+                ok = 0.0
+        if float(allreduce_max(np.array([1.0 - ok]))[0]) > 0.0:  # (some rank could not cut its interior: nobody uses it)
+            return False
+        keep = dict(interior=i32(piece.interior), gl=i32(piece.gamma_owned_local), gg=i32(piece.gamma_owned_gid),
+                    gi=(i32(piece.A_GI.indptr), i32(piece.A_GI.indices), f64(piece.A_GI.data)),
+                    ig=(i32(piece.A_IG.indptr), i32(piece.A_IG.indices), f64(piece.A_IG.data)))
+        desc = _lib.SchurPiece(
+            n_interior=piece.n_interior, n_gamma=piece.n_gamma, n_gamma_owned=len(keep["gl"]), interior=p_i32(keep["interior"]),
+            gamma_owned_local=p_i32(keep["gl"]) if len(keep["gl"]) else None, gamma_owned_gid=p_i32(keep["gg"]) if len(keep["gg"]) else None,
+            gi_indptr=p_i32(keep["gi"][0]), gi_indices=p_i32(keep["gi"][1]), gi_data=p_f64(keep["gi"][2]),
+            ig_indptr=p_i32(keep["ig"][0]), ig_indices=p_i32(keep["ig"][1]), ig_data=p_f64(keep["ig"][2]))
+        status = self._lib.tdgl_poisson_schur_begin(self._ctx, C.byref(desc))
+        t_dev = 0.0
+        if status == _lib.TDGL_OK:
+            status, t_dev = self._upload_levels(levels, packed)
+        ng = int(piece.n_gamma)
+        S = np.zeros((ng, ng))
+        if status == _lib.TDGL_OK:
+            Cmat = np.zeros((ng, ng))
+            status = self._lib.tdgl_poisson_schur_complement(self._ctx, p_f64(Cmat))
+            S = piece.A_GG_owned.toarray() - Cmat
+        failed = float(allreduce_max(np.array([0.0 if status == _lib.TDGL_OK else 1.0]))[0]) > 0.0
+        if failed:
+            if status != _lib.TDGL_OK:
+                err = self._lib.tdgl_last_error(self._ctx)
+                self.setup_times["substructure_error"] = err.decode() if isinstance(err, bytes) else str(err)
+            self._chk(self._lib.tdgl_poisson_set_substructure(self._ctx, None, None))
+            return False
+        with _Stopwatch(self.setup_times, "schur_sum"):
+            S = np.ascontiguousarray(allreduce_sum(S))
+        ta, tv = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self._lib.tdgl_poisson_schur_finish(self._ctx, p_f64(S), 1, C.byref(ta), C.byref(tv)))
+        times = allreduce_max(np.array([ta.value, tv.value]))
+        self._chk(self._lib.tdgl_poisson_set_precond_times(self._ctx, float(times[0]), float(times[1])))
+        self._chk(self._lib.tdgl_poisson_precond_choice(self._ctx, int(self.PD_CHOICE if choice is None else choice)))
+        self.setup_times["substructure_device"] = t_dev
+        entries = sum(g.size for lv in levels for g in lv.G) + sum(e.size for lv in levels for e in lv.E)
+        self.precond_direct = dict(
+            kind="rank-level nested dissection", levels=len(levels), storage="fp32", interior=int(piece.n_interior), interface=ng,
+            interface_owned=int(len(keep["gl"])), parts=levels[0].n_parts, separator=levels[0].n_sep,
+            bytes_per_application=int(2 * (4 * entries + 12 * sum(lv.coupling.nnz for lv in levels)) + 4 * ng * ng // 2
+                                      + 12 * (piece.A_GI.nnz + piece.A_IG.nnz)),
+            allreduce_doubles_per_application=ng, t_apply_us=round(float(times[0]), 1), t_vcycle_us=round(float(times[1]), 1))
+        self.precond_direct_stats(reset=True)
+        return True
+
     def precond_direct_stats(self, reset=False):
         """`tdgl_get_precond_direct_stats`: solves / CG iterations by preconditioner since the last reset, the measured
         time per application of either, the decades per application observed with the factors."""

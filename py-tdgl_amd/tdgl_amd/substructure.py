@@ -356,12 +356,14 @@ def _schur_sparse(level: Substructure, A_level: sp.spmatrix) -> sp.csr_matrix:
     return (0.5 * (S + S.T)).tocsr()
 
 
-def build_substructure_levels(A: sp.spmatrix, ptrs) -> List[Substructure]:
+def build_substructure_levels(A: sp.spmatrix, ptrs, gauge: bool = True) -> List[Substructure]:
     """Factors of a dissection with ``len(ptrs)`` levels (pointer arrays as `substructure_order3` returns them): level
     k is `build_substructure` applied to level k - 1's Schur complement, the gauge functional is handed down as weights,
-    only the last level forms its Schur complement densely; every level carries its sparse ``coupling`` block."""
+    only the last level forms its Schur complement densely; every level carries its sparse ``coupling`` block.
+    ``gauge=False``: ``A`` is positive definite (a rank's interior block, `schur_dd`): no functional is carried (all
+    weights zero, so the device's mean comes out as zero) and the last level's complement is inverted as it is."""
     A_level = A.tocsr()
-    levels, weights, offset = [], None, 0
+    levels, weights, offset = [], (None if gauge else np.zeros(A_level.shape[0])), 0
     for k, ptr in enumerate(ptrs):
         last = k == len(ptrs) - 1
         lv = build_substructure(A_level, np.asarray(ptr, dtype=np.int64) - offset, weights=weights, with_schur=last)
@@ -369,7 +371,7 @@ def build_substructure_levels(A: sp.spmatrix, ptrs) -> List[Substructure]:
         lv.coupling = A_level[nI:, :nI].tocsr()
         levels.append(lv)
         if not last:
-            weights = (1.0 + lv.u) if k == 0 else lv.u  # (first level: v = 1_S - sum E^T 1; further down: u itself is the functional)
+            weights = (1.0 + lv.u) if (k == 0 and gauge) else lv.u  # (first level: v = 1_S - sum E^T 1; further down: u itself is the functional)
             A_level = _schur_sparse(lv, A_level)
             offset += nI
     return levels

@@ -79,7 +79,11 @@ def _worker(rank, world, port, transport, out_dir, overlap=True, size=(60, 15), 
                      deep_sizes=np.array([0] * 4 if dp is None else [dp.n_ext - dp.n_own, dp.l1_own, dp.l1_loc, dp.M.shape[0]]),
                      theta_probe=res["theta"], iters=res["pcg_iters"], overlap=on, interior_rows=rows,
                      n_own=run.lp.n_own, n_interior=run.lp.n_interior, gram=run.ctx.guess_gram(),
-                     retries=run.ctx.step_stats()["psi_retries"], **fields)
+                     retries=run.ctx.step_stats()["psi_retries"], allreduces=comm["allreduces"],
+                     schur=np.array([0, 0, 0, 0, 0, 0] if run.schur is None else
+                                    [1, run.schur["interface"], run.schur["levels"], run.ctx.precond_direct_stats()["solves_factors"],
+                                     run.ctx.precond_direct_stats()["iterations_factors"], run.ctx.precond_direct_stats()["solves_vcycle"]]),
+                     **fields)
         run.close()
     finally:
         dist.destroy_process_group()
@@ -121,6 +125,35 @@ def test_multi_rank_run_matches_single_gpu(world, transport, tmp_path):
     assert np.abs((got["mu_probe"][:, 0] - got["mu_probe"][:, 1]) - (ref_res["mu"][:, 0] - ref_res["mu"][:, 1])).max() < 1e-9
     # the decomposition must not change the iteration count materially
     assert abs(got["iters"].mean() - ref_res["pcg_iters"].mean()) < 2.0
+
+
+@pytest.mark.parametrize("world,transport,choice", [(2, "gloo", 1), (3, "ipc", 1), (8, "ipc", 1), (3, "ipc", 0)])
+def test_rank_level_dissection_as_the_preconditioner_matches_single_gpu(world, transport, choice, tmp_path):
+    """`tdgl_amd/schur_dd.py`, `csrc/schur.inc`: the cut between the ranks as the top level of a nested dissection --
+    every rank holds the fp32-stored factors of its interior block, all hold the pseudo-inverse of the interface
+    complement -- as the CG's second preconditioner in one-process-per-GPU mode.  12.7k sites on 2 / 3 / 8 ranks
+    sharing one GPU, every solve through the factors (choice 1) or the cheaper preconditioner per solve (choice 0),
+    against the single-GPU run: the same trajectory at 1e-9, ONE or two CG iterations per solve, and per step a handful
+    of sums where the distributed AMG cycle needs two per iteration."""
+    size, kw = (130, 95), dict(b=0.3)
+    mesh, ref_res, ref = _single_gpu_reference(size, kw)
+    mp.spawn(_worker, args=(world, _free_port(), transport, str(tmp_path), True, size, kw,
+                            dict(schur=True, schur_blocks=(60, 500, 3000), schur_choice=choice)), nprocs=world, join=True)
+    got = np.load(os.path.join(tmp_path, f"dist_{transport}_{world}.npz"))
+    on, n_gamma, levels, solves_f, iters_f, solves_v = (int(v) for v in got["schur"])
+    assert on == 1 and levels >= 1 and 0.5 * np.sqrt(len(mesh.sites)) < n_gamma < 6 * world * np.sqrt(len(mesh.sites))
+    assert len(got["dt"]) == N_STEPS
+    assert np.abs(got["dt"] - ref_res["dt"]).max() <= 1e-9 * ref_res["dt"].max()
+    assert np.abs(np.abs(got["psi"]) ** 2 - np.abs(ref["psi"]) ** 2).max() < 1e-9
+    assert np.abs(got["mu"] - ref["mu"]).max() < 1e-9 * max(1.0, np.abs(ref["mu"]).max())
+    assert np.abs(got["supercurrent"] - ref["supercurrent"]).max() < 1e-9
+    assert np.abs(got["normal_current"] - ref["normal_current"]).max() < 1e-9
+    if choice == 1:
+        assert solves_v == 0 and solves_f == N_STEPS and iters_f <= 2 * N_STEPS and got["iters"].max() <= 2
+        # per step: the Gram sum, the status MAX, per iteration the interface sum and the CG's sum, the gauge
+        assert got["allreduces"] / N_STEPS < 8.0
+    else:
+        assert solves_f + solves_v == N_STEPS and solves_f >= 1
 
 
 @pytest.mark.parametrize("transport", ["gloo", "ipc"])
@@ -328,7 +361,11 @@ def _soak_worker(rank, world, port, transport, out_dir, steps):
         fields = run.gather_state()
         if rank == 0:
             np.savez(os.path.join(out_dir, f"soak_{transport}.npz"), dt=res["dt"], iters=res["pcg_iters"],
-                     retries=run.ctx.step_stats()["psi_retries"], **fields)
+                     retries=run.ctx.step_stats()["psi_retries"], allreduces=comm["allreduces"],
+                     schur=np.array([0, 0, 0, 0, 0, 0] if run.schur is None else
+                                    [1, run.schur["interface"], run.schur["levels"], run.ctx.precond_direct_stats()["solves_factors"],
+                                     run.ctx.precond_direct_stats()["iterations_factors"], run.ctx.precond_direct_stats()["solves_vcycle"]]),
+                     **fields)
         run.close()
     finally:
         dist.destroy_process_group()
