@@ -344,6 +344,10 @@ def main():
     ap.add_argument("--dist-levels", type=int, choices=[1, 2], default=2,
                     help="decomposed runs: 2 (default) = levels 0 and 1 of the AMG hierarchy distributed, one vector exchange "
                          "per PCG iteration (partition.DeepPlanner); 1 = level 0 only, everything below replicated (rounds 1-4)")
+    ap.add_argument("--schur", choices=["auto", "on", "off"], default="auto",
+                    help="decomposed runs: rank-level nested dissection (every rank's interior factors in fp32 + the replicated "
+                         "interface complement) as the CG's second preconditioner -- ONE all-reduce of |Gamma| doubles per application; "
+                         "auto = from 100k sites on (tdgl_amd/schur_dd.py)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="use the domain-decomposition driver (RCCL communicator) even on one GPU")
     ap.add_argument("--config5", choices=["auto", "on", "off"], default="auto",
@@ -461,7 +465,8 @@ def main():
                             raise RuntimeError("made to fail (--debug-fail)")
                         d = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
                                             rank=rank, world=world, transport=tr, device_id=local_rank, root=0,
-                                            deep="auto" if args.dist_levels == 2 else False, payload=payload)
+                                            deep="auto" if args.dist_levels == 2 else False, payload=payload,
+                                            schur=dict(auto="auto", on=True, off=False)[args.schur])
                         box["drun"] = d
                         rep = d.selftest() if (args.selftest == "on" and world > 1) else dict(ok=True, skipped=True)
                         box["rep"] = rep
@@ -877,6 +882,13 @@ def main():
                 if dp is None else
                 "levels 0 and 1 distributed (per-rank aggregates), levels >= 2 replicated: per iteration ONE exchange of the "
                 "residual on a deep ghost zone, a level-2-sized sum, the CG's dot products")
+            sch = getattr(r.drun, "schur", None)
+            if sch is not None:
+                d["comm_per_step"]["decomposition"] += (
+                    "; second preconditioner: rank-level nested dissection (each rank's interior factors in fp32, the interface "
+                    "complement's pseudo-inverse on every rank) -- per application ONE all-reduce of |Gamma| doubles, chosen per solve "
+                    "against the AMG cycle by predicted cost")
+                d["comm_per_step"]["rank_level_dissection"] = dict(sch, **r.ctx.precond_direct_stats())
             if dp is not None:
                 d["comm_per_step"].update(
                     deep_ghost_entries=int(dp.n_ext - dp.n_own), deep_neighbours=len(set(dp.neighbors) | set(dp.send_idx)),
