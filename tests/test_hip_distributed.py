@@ -361,11 +361,7 @@ def _soak_worker(rank, world, port, transport, out_dir, steps):
         fields = run.gather_state()
         if rank == 0:
             np.savez(os.path.join(out_dir, f"soak_{transport}.npz"), dt=res["dt"], iters=res["pcg_iters"],
-                     retries=run.ctx.step_stats()["psi_retries"], allreduces=comm["allreduces"],
-                     schur=np.array([0, 0, 0, 0, 0, 0] if run.schur is None else
-                                    [1, run.schur["interface"], run.schur["levels"], run.ctx.precond_direct_stats()["solves_factors"],
-                                     run.ctx.precond_direct_stats()["iterations_factors"], run.ctx.precond_direct_stats()["solves_vcycle"]]),
-                     **fields)
+                     retries=run.ctx.step_stats()["psi_retries"], **fields)
         run.close()
     finally:
         dist.destroy_process_group()
