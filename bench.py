@@ -946,6 +946,19 @@ def main():
             avg_solve_ms=round(avg_ms, 5), samples=main_run.direct[0], event_pair_overhead_ms=round(main_run.ev_over, 5),
             note="launch sequence bracketed by one HIP event pair per batch of the run-ahead loop (the pair's own overhead included)",
         )
+    # 0.4 - 1.3M sites: one application of the fp32-stored factors as the CG's preconditioner (gather, the solve's launch
+    # sequence, scatter), bracketed by an event pair each (the first 64 of the timed window); bytes = what is streamed once
+    roofline_precond = None
+    if rank == 0 and main_run.direct[0] > 0 and main_run.setup.get("precond_direct"):
+        pdi = main_run.setup["precond_direct"]
+        avg_ms = main_run.direct[1] / main_run.direct[0]
+        roofline_precond = dict(
+            bound="hbm", kernel="one application of the nested-dissection factors (fp32 storage) as preconditioner: k_pd_gather + "
+                                "k_sub_down_lanes x 3 + sparse couplings x 3 + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x 3 + k_pd_scatter",
+            achieved=round(pdi["bytes_per_application"] / (avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+            frac=round(pdi["bytes_per_application"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), bytes_per_application=int(pdi["bytes_per_application"]),
+            avg_application_ms=round(avg_ms, 5), samples=main_run.direct[0], event_pair_overhead_ms=round(main_run.ev_over, 5),
+            note="share of the step: applications per step x this time / ms_per_step; the pair's own overhead included")
     r = main_run
     desc = WORKLOADS[args.workload][1]
     strip = isinstance(WORKLOADS[args.workload][0], tuple)
@@ -985,6 +998,7 @@ def main():
         roofline=main_line["roofline"],
         roofline_pcg=roofline_pcg,
         roofline_direct=roofline_direct,
+        roofline_precond=roofline_precond,
         pcg=main_line["pcg"],
         step_aggregate=main_line["step_aggregate"],
         # what a step costs the host: synchronisations and repeated psi updates in the timed window

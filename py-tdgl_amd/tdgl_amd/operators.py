@@ -35,9 +35,11 @@ class _DeviceOperator:
 class MeshOperators:
     """Finite-volume operators for a mesh, resident on the MI355X.
 
-    Args (as in the reference, operators.py:245-252): ``mesh``, ``sparse_solver`` (ignored:
-    the mu solve is always AMG-PCG), ``use_cupy`` (ignored), ``fixed_sites``, ``fix_psi``.
-    Extra keyword arguments configure the device and the Poisson solve.
+    Args (as in the reference, operators.py:245-252): ``mesh``, ``sparse_solver`` (the reference's names select
+    nothing here: the mu solve is chosen by mesh size -- explicit pseudo-inverse, one to three levels of nested
+    dissection, CG with the AMG V-cycle and the fp32-stored factors as its two preconditioners, AMG-PCG alone;
+    `hipcore.TDGLContext.build_poisson` -- and ``"amg_pcg"`` forces the last of these at every size), ``use_cupy``
+    (ignored), ``fixed_sites``, ``fix_psi``.  Extra keyword arguments configure the device and the Poisson solve.
     """
 
     def __init__(
