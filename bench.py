@@ -458,15 +458,20 @@ def main():
             payload, alive = None, {}
             for tr in candidates:
                 box = {}
+                # every candidate's host-side collectives (piece scatter, handle exchange, the sums of the rank-level
+                # dissection's set-up, the meeting before a batch) run on a process group of ITS OWN, made here on the main
+                # thread: a collective still pending in a watchdog thread that was abandoned can then never pair with the
+                # main thread's next collective on the default group
+                cand_group = dist.new_group(backend="gloo") if world > 1 else None
 
-                def attempt(tr=tr, box=box, payload=payload):
+                def attempt(tr=tr, box=box, payload=payload, cand_group=cand_group):
                     try:
                         if tr in args.debug_fail.split(","):
                             raise RuntimeError("made to fail (--debug-fail)")
                         d = DistributedTDGL(None if wl is None else wl.mesh, opts, None if wl is None else wl.A, 1.0,
                                             rank=rank, world=world, transport=tr, device_id=local_rank, root=0,
                                             deep="auto" if args.dist_levels == 2 else False, payload=payload,
-                                            schur=dict(auto="auto", on=True, off=False)[args.schur])
+                                            schur=dict(auto="auto", on=True, off=False)[args.schur], group=cand_group)
                         box["drun"] = d
                         rep = d.selftest() if (args.selftest == "on" and world > 1) else dict(ok=True, skipped=True)
                         box["rep"] = rep
@@ -495,6 +500,8 @@ def main():
                     payload = box["drun"].payload  # (the next candidate reuses the piece this rank already received)
                 rep = dict(box.get("rep") or dict(ok=False))
                 if not finished:
+                    # (fatal for this candidate on EVERY rank: its group is never used again, its context keeps spinning
+                    # kernels bounded by the transport's own time-out)
                     rep.update(ok=False, error=f"did not finish within {args.transport_timeout} s (abandoned)")
                 elif "error" in box:
                     rep.update(ok=False, error=box["error"])

@@ -324,8 +324,11 @@ int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const i
  *     observed for each, times what one application was MEASURED to take on this device at this call (*t_apply_us for
  *     the factors, *t_vcycle_us for the AMG V-cycle; may be NULL).
  * tdgl_poisson_precond_choice: 0 = by predicted cost (default), 1 = always the factors, 2 = never (tests, A/B runs).
- * tdgl_get_precond_direct_stats: out4 = {solves with the factors, their CG iterations, solves with the V-cycle, their
- * iterations} since the last reset, out3 = {t_apply_us, t_vcycle_us, decades per application observed}. */
+ * A solve that the factors leave just above the tolerance is FINISHED by the V-cycle when that is predicted cheaper than a
+ * second application (the same rule on the residual that is left; the CG restarts from the iterate with beta = 0).
+ * tdgl_get_precond_direct_stats: out4 = {solves that began with the factors, CG iterations taken with the factors, solves
+ * with the V-cycle alone, iterations taken with the V-cycle (hand-overs included)} since the last reset, out4d =
+ * {t_apply_us, t_vcycle_us, decades per application observed, hand-overs since the last reset}. */
 int tdgl_poisson_set_substructure_precond(tdgl_ctx *ctx, const int32_t *site_map, int32_t fp32_storage, double *t_apply_us,
                                           double *t_vcycle_us);
 int tdgl_poisson_precond_choice(tdgl_ctx *ctx, int32_t mode);
@@ -362,7 +365,7 @@ int tdgl_poisson_schur_begin(tdgl_ctx *ctx, const tdgl_schur_piece *piece);
 int tdgl_poisson_schur_complement(tdgl_ctx *ctx, double *out);
 int tdgl_poisson_schur_finish(tdgl_ctx *ctx, const double *S, int32_t fp32_storage, double *t_apply_us, double *t_vcycle_us);
 int tdgl_poisson_set_precond_times(tdgl_ctx *ctx, double t_apply_us, double t_vcycle_us);
-int tdgl_get_precond_direct_stats(tdgl_ctx *ctx, int64_t *out4, double *out3, int32_t reset);
+int tdgl_get_precond_direct_stats(tdgl_ctx *ctx, int64_t *out4, double *out4d, int32_t reset);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
  * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep

@@ -409,6 +409,7 @@ struct tdgl_ctx {
     double pd_t_apply_us = 0.0, pd_t_vcycle_us = 0.0;  // measured at set-up: one application of either preconditioner
     int64_t pd_solves = 0, pd_iters = 0, pd_amg_solves = 0, pd_amg_iters = 0;  // solves / iterations by preconditioner since the last reset
     bool pd_last = false;                 // the last solve used the factors
+    int64_t pd_handovers = 0;             // solves that began with the factors and were finished by the V-cycle
     // Rank-level nested dissection (one process per GPU; schur.inc, tdgl_poisson_schur_begin / _complement / _finish): the
     // resident factors are those of THIS RANK'S INTERIOR block A_II (sub_n_local sites in the local dissection order, positive
     // definite: plain inverse of the top separator, no gauge), Gamma = the interface between the ranks (schur_ng sites,

@@ -190,10 +190,15 @@ class DistributedTDGL:
     def __init__(self, mesh, options, link_exponents=None, epsilon=1.0, u=5.79, gamma=10.0, *, rank, world,
                  terminal_info=(), mu_boundary=None, probe_points=None, transport="rccl", device_id=None,
                  overlap="auto", screening=None, root=None, payload=None, max_coarse=None, deep="auto", plan_kw=None,
-                 schur="auto", schur_blocks=None, schur_choice=None):
+                 schur="auto", schur_blocks=None, schur_choice=None, group=None):
+        """``group``: the process group every host-side collective of this object runs on (default: the default group).  A
+        launcher that sets candidates up inside watchdog threads it may abandon (bench.py's transport race) gives each
+        candidate its OWN group (`dist.new_group()` on the main thread), so that a collective still pending in an abandoned
+        thread can never pair with the main thread's next collective."""
         import torch.distributed as dist
 
         self.dist = dist
+        self.group = group
         self.rank, self.world = int(rank), int(world)
         if self.world > 1:
             limit_host_threads(self.world)
@@ -212,7 +217,7 @@ class DistributedTDGL:
                                               screening=screening, max_coarse=max_coarse, deep=deep, plan_kw=plan_kw)
                 if self.world > 1:
                     got = [None]
-                    dist.scatter_object_list(got, pieces, src=int(root))
+                    dist.scatter_object_list(got, pieces, src=int(root), group=group)
                     payload = got[0]
                 else:
                     payload = pieces[0]
@@ -233,7 +238,7 @@ class DistributedTDGL:
         if self.world > 1 or transport in ("rccl", "ipc"):  # (one rank: the decomposed sequence with world = 1)
             if transport == "rccl":
                 ident = [ctx.comm_unique_id() if self.rank == 0 else None]
-                dist.broadcast_object_list(ident, src=0)
+                dist.broadcast_object_list(ident, src=0, group=group)
                 with stdout_to_stderr():
                     ctx.comm_init_rccl(ident[0])
             elif transport == "ipc":
@@ -241,7 +246,7 @@ class DistributedTDGL:
                 mine = ctx.comm_ipc_export(self.world)
                 everyone = [None] * self.world
                 if self.world > 1:
-                    dist.all_gather_object(everyone, mine)
+                    dist.all_gather_object(everyone, mine, group=group)
                 else:
                     everyone = [mine]
                 ctx.comm_init_ipc([e[0] for e in everyone], [e[1] for e in everyone])
@@ -294,7 +299,7 @@ class DistributedTDGL:
             def reducer(op):
                 def f(a):
                     t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
-                    dist.all_reduce(t, op=op)
+                    dist.all_reduce(t, op=op, group=group)
                     return t.numpy()
                 return f
 
@@ -317,10 +322,10 @@ class DistributedTDGL:
             t = torch.empty(int(recv_off[k + 1] - recv_off[k]), dtype=torch.float64)
             bufs.append(t)
             if t.numel():
-                reqs.append(dist.irecv(t, src=int(nb)))
+                reqs.append(dist.irecv(t, src=int(nb), group=self.group))
         for k, nb in enumerate(ranks):
             if send_off[k + 1] > send_off[k]:
-                reqs.append(dist.isend(torch.from_numpy(send[send_off[k]:send_off[k + 1]].copy()), dst=int(nb)))
+                reqs.append(dist.isend(torch.from_numpy(send[send_off[k]:send_off[k + 1]].copy()), dst=int(nb), group=self.group))
         for r in reqs:
             r.wait()
         for k in range(len(ranks)):
@@ -330,7 +335,7 @@ class DistributedTDGL:
         import torch
 
         t = torch.from_numpy(buf.copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX, group=self.group)
         buf[:] = t.numpy()
 
     # -- first contact ----------------------------------------------------------------------------
@@ -413,7 +418,7 @@ class DistributedTDGL:
         are bounded (`tdgl_comm_ipc_set_timeout`; two minutes unless told otherwise), and nothing else bounds the skew
         between ranks -- one of them saving a snapshot, a slow file system -- so the host takes it out here."""
         if self.world > 1 and self.transport == "ipc":
-            self.dist.barrier()
+            self.dist.barrier(group=self.group)
 
     def run(self, max_steps, end_time=np.inf, host_barrier=True):
         """``host_barrier=False`` skips the meeting above (tests of the device-side time-out)."""
@@ -432,7 +437,7 @@ class DistributedTDGL:
             import torch
 
             flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32)
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX, group=self.group)
             if failure is not None:
                 raise failure
             if int(flag.item()):
@@ -446,7 +451,7 @@ class DistributedTDGL:
                 both[0][:, self._probe_mine] = res["mu"]
                 both[1][:, self._probe_mine] = res["theta"]
             t = torch.from_numpy(both)
-            self.dist.all_reduce(t)
+            self.dist.all_reduce(t, group=self.group)
             res["mu"], res["theta"] = t.numpy()[0], t.numpy()[1]
         return res
 
@@ -470,7 +475,7 @@ class DistributedTDGL:
         if self.world > 1:
             for arr in (sites, edges):
                 t = torch.from_numpy(arr)
-                self.dist.all_reduce(t)
+                self.dist.all_reduce(t, group=self.group)
         out = dict(psi=sites[0] + 1j * sites[1], mu=sites[2], supercurrent=edges[0], normal_current=edges[1])
         if self.screening is not None:
             out["induced_vector_potential"] = np.column_stack([edges[2], edges[3]])

@@ -263,6 +263,10 @@ class TDGLContext:
             or 2 <= self.n <= (self.DENSE_MAX_SITES if dense_max_sites is None else int(dense_max_sites))))
         if amg_candidates is None:
             amg_candidates = self.AMG_CANDIDATES if (iterative and self.n >= self.AMG_CANDIDATES_MIN_SITES) else 1
+            # (with the factors as second preconditioner the V-cycle only runs where the guess is good -- two or three
+            # iterations per solve --, and 3 % fewer of those do not pay for two more hierarchies: 4.5 s of set-up at 1M sites)
+            if self._pd_order is not None and dense_max_sites is None and self.direct_solve:
+                amg_candidates = 1
         if self.n_owned != self.n:
             amg_candidates = 1
         best, scores = None, []
@@ -583,10 +587,10 @@ class TDGLContext:
     def precond_direct_stats(self, reset=False):
         """`tdgl_get_precond_direct_stats`: solves / CG iterations by preconditioner since the last reset, the measured
         time per application of either, the decades per application observed with the factors."""
-        o4, o3 = (C.c_int64 * 4)(), (C.c_double * 3)()
+        o4, o3 = (C.c_int64 * 4)(), (C.c_double * 4)()
         self._chk(self._lib.tdgl_get_precond_direct_stats(self._ctx, o4, o3, int(bool(reset))))
         return dict(solves_factors=int(o4[0]), iterations_factors=int(o4[1]), solves_vcycle=int(o4[2]), iterations_vcycle=int(o4[3]),
-                    t_apply_us=round(o3[0], 1), t_vcycle_us=round(o3[1], 1), decades_per_application=round(o3[2], 2))
+                    handovers=int(o3[3]), t_apply_us=round(o3[0], 1), t_vcycle_us=round(o3[1], 1), decades_per_application=round(o3[2], 2))
 
     def precond_choice(self, mode: int):
         """0: the library chooses per solve by predicted cost, 1: always the factors, 2: always the AMG V-cycle."""

@@ -156,6 +156,22 @@ def test_rank_level_dissection_as_the_preconditioner_matches_single_gpu(world, t
         assert solves_f + solves_v == N_STEPS and solves_f >= 1
 
 
+def test_peer_mapped_transport_with_fences_gives_the_same_bits(tmp_path, monkeypatch):
+    """`TDGL_IPC_FENCES=1`: the peer-mapped transport with the documented system-scope release / acquire fences around
+    every flag instead of its fence-free ordering (write-through payload stores drained before the flag, cache-bypassing
+    loads behind the flag's branch) -- the same trajectory to the last bit on three ranks, which is what the fence-free form
+    has to deliver; the switch exists so that a multi-GPU node can validate the ordering over xGMI the same way."""
+    out = {}
+    for fences in ("0", "1"):
+        monkeypatch.setenv("TDGL_IPC_FENCES", fences)
+        d = tmp_path / fences
+        d.mkdir()
+        mp.spawn(_worker, args=(3, _free_port(), "ipc", str(d)), nprocs=3, join=True)
+        out[fences] = np.load(os.path.join(d, "dist_ipc_3.npz"))
+    for key in ("dt", "psi", "mu", "supercurrent", "normal_current", "iters"):
+        assert np.array_equal(out["0"][key], out["1"][key]), key
+
+
 @pytest.mark.parametrize("transport", ["gloo", "ipc"])
 def test_more_ranks_than_the_exact_gather_holds(transport, tmp_path, monkeypatch):
     """Beyond 16 ranks the guess's double-double totals are not gathered rank by rank: hi and lo parts are
