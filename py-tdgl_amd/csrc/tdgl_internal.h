@@ -165,6 +165,12 @@ struct SubUpChunk {
 struct SubDownChunk {
     int64_t g;
     int32_t x0, ncols, row0, n_rows;
+    int32_t ld, pad;  // (lane-per-row form: distance between consecutive rows of the part's G block in the pool; == ncols unless repacked)
+};
+// one part of a level while its fp64 pool is repacked into the padded fp32 pool (k_sub_repack)
+struct SubRepack {
+    int64_t old_g, new_g, old_et, new_et;
+    int32_t np, sp, ld, pad;
 };
 struct SubDownRow {
     int32_t nseg, pad;
