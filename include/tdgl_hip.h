@@ -306,33 +306,6 @@ int tdgl_poisson_set_substructure_inner(tdgl_ctx *ctx, const tdgl_substructure *
  * wait), so that a restart from a checkpoint takes the same path whatever preceded it.  While the direct solve is paused
  * mu meets pcg_rtol (the iterative solve's tolerance) instead of the factors' ~1e-14. */
 int tdgl_direct_switching(tdgl_ctx *ctx, int32_t on, int64_t *switches, int32_t *paused);
-/* The FIRST level through banded Cholesky factors instead of dense blocks (round 6).  Its parts are sparse matrices --
- * 130-160 mesh sites in reverse Cuthill-McKee order, bandwidth 8-21 --, whose explicit inverses G_p and E_p = G_p A_pS
- * are 60 % of what a solve streams at a million sites; their factors are a tenth of that, and a triangular solve with
- * them runs inside ONE wavefront (kernels.inc: k_leaf_down / k_leaf_up: a sliding window of rows over the 64 lanes,
- * column-oriented substitution, no reduction across lanes, the band staged in LDS).  Way down: y_p = A_pp^-1 b_p and
- * sum(y_p), the part's share of the gauge functional; way up: x_p = A_pp^-1 (b_p - A_pS x_S), a second solve in place
- * of the dense E_p.  Takes the place of tdgl_poisson_set_substructure for the first level (the levels above, the
- * coupling block of level 0 -- required --, the preconditioner / rank-level calls as before).
- *   lc[band_off[p] + i w + k] = L_p[i + k][i] (k >= 1), lr[... + i w + k] = L_p[i][i - k], [... + i w] = 1 / L_p[i][i]
- *   with w = band_w[p] <= 64 entries per row, zero outside the matrix; n_p <= 256 rows per part;
- *   gauge: 1 = the level carries sum(y_p) per part (singular matrix: weights one), 0 = none (positive definite);
- *   is_*: A_IS [n_interior x n_sep] CSR; u [n_sep] as in tdgl_substructure; schur: optional, as there. */
-typedef struct {
-    int64_t n_interior, n_sep;
-    int32_t n_parts;
-    const int32_t *part_ptr;
-    const int64_t *band_off;
-    const int32_t *band_w;
-    const double *lc, *lr;
-    int64_t n_band;
-    int32_t gauge;
-    const double *u;
-    const int32_t *is_indptr, *is_indices;
-    const double *is_data;
-    const double *schur;
-} tdgl_substructure_banded;
-int tdgl_poisson_set_substructure_banded(tdgl_ctx *ctx, const tdgl_substructure_banded *sub, double *seconds);
 int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const int32_t *indptr, const int32_t *indices,
                                            const double *data);
 /* The resident factors (every level and coupling block described) as the PRECONDITIONER of the CG instead of as the

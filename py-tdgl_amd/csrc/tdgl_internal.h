@@ -172,10 +172,6 @@ struct SubRepack {
     int64_t old_g, new_g, old_et, new_et;
     int32_t np, sp, ld, pad;
 };
-struct LeafPart {       // one part of the banded leaf level (kernels.inc: k_leaf_down / k_leaf_up)
-    int64_t off;        // where its band rows start in lc / lr (entries)
-    int32_t row0, np, w, pad;
-};
 struct SubDownRow {
     int32_t nseg, pad;
     int64_t val[4];
@@ -420,15 +416,6 @@ struct tdgl_ctx {
     int64_t pd_solves = 0, pd_iters = 0, pd_amg_solves = 0, pd_amg_iters = 0;  // solves / iterations by preconditioner since the last reset
     bool pd_last = false;                 // the last solve used the factors
     int64_t pd_handovers = 0;             // solves that began with the factors and were finished by the V-cycle
-    // Banded leaf level (tdgl_poisson_set_substructure_banded): the first level's parts through their banded Cholesky
-    // factors, a triangular solve per part inside one wavefront (kernels.inc: k_leaf_down / k_leaf_up), instead of
-    // the dense G_p / E_p blocks of the pool
-    bool sub_banded = false;
-    int leaf_gauge = 0, leaf_lds_entries = 0;
-    tdgl::DevBuf<tdgl::LeafPart> leaf_parts;
-    tdgl::DevBuf<double> leaf_lc, leaf_lr;
-    tdgl::DevBuf<float> leaf_lc32, leaf_lr32;
-    tdgl::Csr leaf_IS;                     // A_IS [n_interior x n_sep]
     // Rank-level nested dissection (one process per GPU; schur.inc, tdgl_poisson_schur_begin / _complement / _finish): the
     // resident factors are those of THIS RANK'S INTERIOR block A_II (sub_n_local sites in the local dissection order, positive
     // definite: plain inverse of the top separator, no gauge), Gamma = the interface between the ranks (schur_ng sites,

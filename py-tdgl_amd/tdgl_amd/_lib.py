@@ -167,28 +167,6 @@ class Substructure(C.Structure):
     ]
 
 
-class SubstructureBanded(C.Structure):
-    """`tdgl_substructure_banded` (include/tdgl_hip.h): the first level through banded Cholesky factors of its parts."""
-
-    _fields_ = [
-        ("n_interior", C.c_int64),
-        ("n_sep", C.c_int64),
-        ("n_parts", C.c_int32),
-        ("part_ptr", c_i32p),
-        ("band_off", C.POINTER(C.c_int64)),
-        ("band_w", c_i32p),
-        ("lc", c_f64p),
-        ("lr", c_f64p),
-        ("n_band", C.c_int64),
-        ("gauge", C.c_int32),
-        ("u", c_f64p),
-        ("is_indptr", c_i32p),
-        ("is_indices", c_i32p),
-        ("is_data", c_f64p),
-        ("schur", c_f64p),
-    ]
-
-
 class SchurPiece(C.Structure):
     """`tdgl_schur_piece` (include/tdgl_hip.h): one rank's share of the rank-level dissection."""
 
@@ -277,7 +255,6 @@ SIGNATURES = {
     "tdgl_poisson_set_substructure_inner": (C.c_int, [_CTX, C.POINTER(Substructure), c_f64p]),
     "tdgl_direct_switching": (C.c_int, [_CTX, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "tdgl_poisson_set_substructure_coupling": (C.c_int, [_CTX, C.c_int32, c_i32p, c_i32p, c_f64p]),
-    "tdgl_poisson_set_substructure_banded": (C.c_int, [_CTX, C.POINTER(SubstructureBanded), c_f64p]),
     "tdgl_poisson_set_substructure_precond": (C.c_int, [_CTX, c_i32p, C.c_int32, c_f64p, c_f64p]),
     "tdgl_poisson_precond_choice": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_poisson_schur_begin": (C.c_int, [_CTX, C.POINTER(SchurPiece)]),

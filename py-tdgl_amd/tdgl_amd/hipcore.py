@@ -240,9 +240,6 @@ class TDGLContext:
     # factors, and the context keeps the reverse Cuthill-McKee order (16-bit column offsets in the stencil kernels).
     PD_MAX_SITES = int(__import__("os").environ.get("TDGL_PD_MAX_SITES", "1300000"))
     PD_CHOICE = 0  # 0: by predicted cost, 1: always the factors, 2: never (tests / A-B runs)
-    # the first level of every host-built dissection through banded Cholesky factors of its parts (a triangular solve per
-    # part inside one wavefront, `tdgl_poisson_set_substructure_banded`) instead of the dense blocks G_p / E_p
-    LEAF_BANDED = __import__("os").environ.get("TDGL_LEAF_BANDED", "1") != "0"
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",
@@ -354,47 +351,19 @@ class TDGLContext:
 
             with _Stopwatch(self.setup_times, "substructure_host"):
                 try:
-                    levels = build_substructure_levels(A, [self._sub_part_ptr, self._sub_super_ptr, self._sub_big_ptr],
-                                                       banded_leaf=self.LEAF_BANDED)
-                    leaf, packed = self._pack_levels(levels, gauge=True)
+                    levels = build_substructure_levels(A, [self._sub_part_ptr, self._sub_super_ptr, self._sub_big_ptr])
+                    packed = [pack_for_device(lv, True) for lv in levels]
                 except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
                     self.setup_times["substructure_error"] = repr(exc)
                     return False
-            status, t_dev = self._upload_levels(levels, packed, leaf)
+            status, t_dev = self._upload_levels(levels, packed)
             sec = C.c_double(t_dev)
             sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
-            dense_levels = levels[1:] if leaf is not None else levels
-            info = dict(levels=3, sparse_separator_rhs=True, leaf="banded Cholesky factors" if leaf is not None else "dense blocks",
-                        parts=levels[0].n_parts, separator=levels[0].n_sep,
+            info = dict(levels=3, sparse_separator_rhs=True, parts=levels[0].n_parts, separator=levels[0].n_sep,
                         super_blocks=levels[1].n_parts, top_separator=levels[1].n_sep, super_super_blocks=levels[2].n_parts,
                         top_top_separator=levels[2].n_sep, built_on="host",
-                        bytes_per_solve=int(sum(8 * g.size for lv in dense_levels for g in lv.G) + sum(8 * e.size for lv in dense_levels for e in lv.E)
-                                            + (32 * leaf["n_band"] if leaf is not None else 0)
+                        bytes_per_solve=int(sum(8 * g.size for lv in levels for g in lv.G) + sum(8 * e.size for lv in levels for e in lv.E)
                                             + 12 * sum(lv.coupling.nnz for lv in levels) + sym(levels[2].n_sep)))
-            del levels, packed
-        elif self._sub_super_ptr is not None and self.LEAF_BANDED:
-            # two levels, the first through banded Cholesky factors of its parts: the generic multi-level path
-            from .substructure import build_substructure_levels
-
-            sparse_sep = self.n >= self.SUB2_SPARSE_SEP_MIN_SITES
-            with _Stopwatch(self.setup_times, "substructure_host"):
-                try:
-                    levels = build_substructure_levels(A, [self._sub_part_ptr, self._sub_super_ptr], banded_leaf=True)
-                    leaf, packed = self._pack_levels(levels, gauge=True, sparse=[True, sparse_sep])
-                except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
-                    self.setup_times["substructure_error"] = repr(exc)
-                    return False
-            status, t_dev = self._upload_levels(levels, packed, leaf, sparse=[True, sparse_sep])
-            sec = C.c_double(t_dev)
-            sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
-            dense_levels = levels[1:] if leaf is not None else levels
-            info = dict(levels=2, sparse_separator_rhs=bool(sparse_sep), leaf="banded Cholesky factors" if leaf is not None else "dense blocks",
-                        parts=levels[0].n_parts, separator=levels[0].n_sep, super_blocks=levels[1].n_parts, top_separator=levels[1].n_sep,
-                        built_on="host",
-                        bytes_per_solve=int(sum(8 * g.size for lv in dense_levels for g in lv.G)
-                                            + (1 if sparse_sep else 2) * sum(8 * e.size for lv in dense_levels for e in lv.E)
-                                            + (32 * leaf["n_band"] if leaf is not None else 0)
-                                            + 12 * sum(lv.coupling.nnz for k, lv in enumerate(levels) if (k == 0 or sparse_sep)) + sym(levels[1].n_sep)))
             del levels, packed
         elif self._sub_super_ptr is not None:
             # two levels: the factors of both are formed on the host, the top separator's pseudo-inverse on the device
@@ -471,21 +440,9 @@ class TDGLContext:
             self.direct_switching(True)
         return True
 
-    def _pack_levels(self, levels, gauge=True, sparse=None):
-        """``(leaf, packed)`` for `_upload_levels`: the first level as bands (`pack_leaf_banded`) when it was built that
-        way and fits the kernels, the others (and the first otherwise) as `pack_for_device` pools; ``sparse[k]``: level k
-        without its -E^T rows on the way down (default: all)."""
-        from .substructure import pack_for_device, pack_leaf_banded
-
-        leaf = pack_leaf_banded(levels[0], gauge) if getattr(levels[0], "Lc", None) else None
-        packed = [None if (k == 0 and leaf is not None) else pack_for_device(lv, True if sparse is None else bool(sparse[k]))
-                  for k, lv in enumerate(levels)]
-        return leaf, packed
-
-    def _upload_levels(self, levels, packed, leaf=None, sparse=None):
-        """The factors of a multi-level dissection (`substructure.build_substructure_levels`, `_pack_levels`)
-        into the library: first level (``leaf``: as bands), inner levels, the levels' sparse coupling blocks (all of them
-        unless ``sparse`` says otherwise).  Returns (status, device seconds)."""
+    def _upload_levels(self, levels, packed):
+        """The factors of a multi-level dissection (`substructure.build_substructure_levels`, `pack_for_device(..., True)`)
+        into the library: first level, inner levels, every level's sparse coupling block.  Returns (status, device seconds)."""
         sec = C.c_double(0.0)
         p_i64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
 
@@ -500,24 +457,12 @@ class TDGLContext:
 
         t_dev, status = 0.0, _lib.TDGL_OK
         for k, pk in enumerate(packed):
-            if k == 0 and leaf is not None:
-                keep = {key: (i32(v) if key in ("part_ptr", "band_w", "is_indptr", "is_indices") else v) for key, v in leaf.items()}
-                d = _lib.SubstructureBanded(
-                    n_interior=leaf["n_interior"], n_sep=leaf["n_sep"], n_parts=leaf["n_parts"], part_ptr=p_i32(keep["part_ptr"]),
-                    band_off=p_i64(keep["band_off"]), band_w=p_i32(keep["band_w"]), lc=p_f64(keep["lc"]), lr=p_f64(keep["lr"]),
-                    n_band=leaf["n_band"], gauge=leaf["gauge"], u=p_f64(keep["u"]), is_indptr=p_i32(keep["is_indptr"]),
-                    is_indices=p_i32(keep["is_indices"]), is_data=p_f64(keep["is_data"]),
-                    schur=None if leaf["schur"] is None else p_f64(leaf["schur"]))
-                status = self._lib.tdgl_poisson_set_substructure_banded(self._ctx, C.byref(d), C.byref(sec))
-            else:
-                call = self._lib.tdgl_poisson_set_substructure if k == 0 else self._lib.tdgl_poisson_set_substructure_inner
-                status = call(self._ctx, C.byref(describe(pk)), C.byref(sec))
+            call = self._lib.tdgl_poisson_set_substructure if k == 0 else self._lib.tdgl_poisson_set_substructure_inner
+            status = call(self._ctx, C.byref(describe(pk)), C.byref(sec))
             t_dev += sec.value
             if status != _lib.TDGL_OK:
                 return status, t_dev
         for k, lv in enumerate(levels):
-            if sparse is not None and not sparse[k] and not (k == 0 and leaf is not None):
-                continue
             M = lv.coupling
             keep_c = (i32(M.indptr), i32(M.indices), f64(M.data))
             status = self._lib.tdgl_poisson_set_substructure_coupling(self._ctx, k, p_i32(keep_c[0]), p_i32(keep_c[1]), p_f64(keep_c[2]))
@@ -540,12 +485,12 @@ class TDGLContext:
         with _Stopwatch(self.setup_times, "substructure_host"):
             try:
                 A_d = poisson_matrix(k["edges"].astype(np.int64), k["dl"] / k["el"], self.n, iperm_d)
-                levels = build_substructure_levels(A_d, [p1, p2, p3], banded_leaf=self.LEAF_BANDED)
-                leaf, packed = self._pack_levels(levels, gauge=True)
+                levels = build_substructure_levels(A_d, [p1, p2, p3])
+                packed = [pack_for_device(lv, True) for lv in levels]
             except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
                 self.setup_times["substructure_error"] = repr(exc)
                 return False
-        status, t_dev = self._upload_levels(levels, packed, leaf)
+        status, t_dev = self._upload_levels(levels, packed)
         ta, tv = C.c_double(0.0), C.c_double(0.0)
         if status == _lib.TDGL_OK:
             keep_map = i32(perm_d)
@@ -557,11 +502,8 @@ class TDGLContext:
             return False
         self.setup_times["substructure_device"] = t_dev
         sym = lambda m: ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
-        dense_levels = levels[1:] if leaf is not None else levels
-        entries = sum(g.size for lv in dense_levels for g in lv.G) + sum(e.size for lv in dense_levels for e in lv.E) + sym(levels[2].n_sep)
-        if leaf is not None:  # (both orientations of the band, in each of the two leaf solves of an application)
-            entries += 4 * leaf["n_band"]
-        info = dict(levels=3, storage="fp32", leaf="banded Cholesky factors" if leaf is not None else "dense blocks", parts=levels[0].n_parts, separator=levels[0].n_sep, super_blocks=levels[1].n_parts,
+        entries = sum(g.size for lv in levels for g in lv.G) + sum(e.size for lv in levels for e in lv.E) + sym(levels[2].n_sep)
+        info = dict(levels=3, storage="fp32", parts=levels[0].n_parts, separator=levels[0].n_sep, super_blocks=levels[1].n_parts,
                     top_separator=levels[1].n_sep, super_super_blocks=levels[2].n_parts, top_top_separator=levels[2].n_sep,
                     bytes_per_application=int(4 * entries + 12 * sum(lv.coupling.nnz for lv in levels) + 2 * 20 * self.n),
                     t_apply_us=round(ta.value, 1), t_vcycle_us=round(tv.value, 1))
@@ -592,8 +534,8 @@ class TDGLContext:
         levels = packed = None
         with _Stopwatch(self.setup_times, "substructure_host"):
             try:
-                levels = build_substructure_levels(piece.A_II, piece.ptrs, gauge=False, banded_leaf=self.LEAF_BANDED)
-                leaf, packed = self._pack_levels(levels, gauge=False)
+                levels = build_substructure_levels(piece.A_II, piece.ptrs, gauge=False)
+                packed = [pack_for_device(lv, True) for lv in levels]
             except (ValueError, IndexError, np.linalg.LinAlgError) as exc:
                 self.setup_times["substructure_error"] = repr(exc)
                 ok = 0.0
@@ -610,7 +552,7 @@ class TDGLContext:
         status = self._lib.tdgl_poisson_schur_begin(self._ctx, C.byref(desc))
         t_dev = 0.0
         if status == _lib.TDGL_OK:
-            status, t_dev = self._upload_levels(levels, packed, leaf)
+            status, t_dev = self._upload_levels(levels, packed)
         ng = int(piece.n_gamma)
         S = np.zeros((ng, ng))
         if status == _lib.TDGL_OK:
@@ -632,13 +574,9 @@ class TDGLContext:
         self._chk(self._lib.tdgl_poisson_set_precond_times(self._ctx, float(times[0]), float(times[1])))
         self._chk(self._lib.tdgl_poisson_precond_choice(self._ctx, int(self.PD_CHOICE if choice is None else choice)))
         self.setup_times["substructure_device"] = t_dev
-        dense_levels = levels[1:] if leaf is not None else levels
-        entries = sum(g.size for lv in dense_levels for g in lv.G) + sum(e.size for lv in dense_levels for e in lv.E)
-        if leaf is not None:
-            entries += 2 * leaf["n_band"]  # (both orientations, per local pass; the passes are doubled below)
+        entries = sum(g.size for lv in levels for g in lv.G) + sum(e.size for lv in levels for e in lv.E)
         self.precond_direct = dict(
-            kind="rank-level nested dissection", levels=len(levels), storage="fp32",
-            leaf="banded Cholesky factors" if leaf is not None else "dense blocks", interior=int(piece.n_interior), interface=ng,
+            kind="rank-level nested dissection", levels=len(levels), storage="fp32", interior=int(piece.n_interior), interface=ng,
             interface_owned=int(len(keep["gl"])), parts=levels[0].n_parts, separator=levels[0].n_sep,
             bytes_per_application=int(2 * (4 * entries + 12 * sum(lv.coupling.nnz for lv in levels)) + 4 * ng * ng // 2
                                       + 12 * (piece.A_GI.nnz + piece.A_IG.nnz)),

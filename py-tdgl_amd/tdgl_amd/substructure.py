@@ -86,50 +86,7 @@ class Substructure:
                 + (sym(self.n_sep) if self.schur is not None else 0))
 
 
-def band_factors(App: np.ndarray):
-    """Banded Cholesky factor of a part's interior block (dense array of a sparse, positive definite matrix in an order
-    of small bandwidth) in the two layouts `tdgl_substructure_banded` takes: ``lc[i, k] = L[i + k, i]`` (column
-    oriented), ``lr[i, k] = L[i, i - k]`` (row oriented), ``[i, 0] = 1 / L[i, i]`` in both, zero outside the matrix."""
-    from scipy.linalg import cholesky_banded
-
-    n = App.shape[0]
-    i, j = np.nonzero(App)
-    bw = int(np.abs(i - j).max()) if len(i) else 0
-    ab = np.zeros((bw + 1, n))
-    for k in range(bw + 1):
-        ab[k, : n - k] = np.diagonal(App, -k)
-    cb = cholesky_banded(ab, lower=True)  # cb[k, j] = L[j + k, j]
-    lc = np.zeros((n, bw + 1))
-    lr = np.zeros((n, bw + 1))
-    lc[:, 0] = lr[:, 0] = 1.0 / cb[0]
-    for k in range(1, bw + 1):
-        lc[: n - k, k] = cb[k, : n - k]
-        lr[k:, k] = cb[k, : n - k]
-    return lc, lr
-
-
-def pack_leaf_banded(sub: "Substructure", gauge: bool):
-    """Flat arrays of `tdgl_substructure_banded` (include/tdgl_hip.h) for a level built with ``banded=True``; None when a
-    part does not fit the kernels (more than 256 rows, more than 64 band entries per row)."""
-    P = sub.n_parts
-    w = np.array([b.shape[1] for b in sub.Lc], dtype=np.int32)
-    sizes = np.diff(sub.part_ptr).astype(np.int64)
-    if P == 0 or sizes.max() > 256 or w.max() > 64 or int((sizes * w).max()) * 8 * 4 > 150 * 1024:
-        return None
-    off = np.concatenate([[0], np.cumsum(sizes * w)]).astype(np.int64)
-    A_IS = sub.coupling.T.tocsr()
-    A_IS.sort_indices()
-    return dict(
-        n_interior=sub.n_interior, n_sep=sub.n_sep, n_parts=P, part_ptr=np.asarray(sub.part_ptr, dtype=np.int32), band_off=off[:-1].copy(),
-        band_w=w, lc=np.ascontiguousarray(np.concatenate([b.ravel() for b in sub.Lc])),
-        lr=np.ascontiguousarray(np.concatenate([b.ravel() for b in sub.Lr])), n_band=int(off[-1]), gauge=int(bool(gauge)),
-        u=np.ascontiguousarray(sub.u), is_indptr=A_IS.indptr.astype(np.int32), is_indices=A_IS.indices.astype(np.int32),
-        is_data=np.ascontiguousarray(A_IS.data, dtype=np.float64), schur=None if sub.schur is None else np.ascontiguousarray(sub.schur),
-    )
-
-
-def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray, weights: np.ndarray = None, with_schur: bool = True,
-                       banded: bool = False) -> Substructure:
+def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray, weights: np.ndarray = None, with_schur: bool = True) -> Substructure:
     """``A`` = the level-0 Poisson matrix in the internal order `substructure_order` produced.
 
     ``weights`` (two-level form, `build_substructure2`): the functional whose value on the solution the factors
@@ -163,8 +120,7 @@ def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray, weights: np.ndarray
         cols = np.unique(ApS.indices)
         B = ApS[:, cols].toarray()
         Ep = Gp @ B
-        band = band_factors(App) if banded else None
-        return Gp, np.ascontiguousarray(Ep), cols.astype(np.int32), B.T @ Ep, band
+        return Gp, np.ascontiguousarray(Ep), cols.astype(np.int32), B.T @ Ep
 
     # the parts are independent: a thread each (LAPACK / BLAS release the GIL; one BLAS thread per call)
     from concurrent.futures import ThreadPoolExecutor
@@ -177,11 +133,8 @@ def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray, weights: np.ndarray
     with threadpool_limits(limits=1):
         with ThreadPoolExecutor(workers) as pool:
             results = list(pool.map(one_part, range(P)))
-    G, E, sidx, Cs, Lc, Lr = [], [], [], [], [], []
-    for p, (Gp, Ep, cols, C, band) in enumerate(results):
-        if band is not None:
-            Lc.append(band[0])
-            Lr.append(band[1])
+    G, E, sidx, Cs = [], [], [], []
+    for p, (Gp, Ep, cols, C) in enumerate(results):
         a, b = int(part_ptr[p]), int(part_ptr[p + 1])
         if with_schur:
             schur[np.ix_(cols, cols)] -= C
@@ -202,7 +155,6 @@ def build_substructure(A: sp.spmatrix, part_ptr: np.ndarray, weights: np.ndarray
         schur = 0.5 * (schur + schur.T)
     out = Substructure(n=n, part_ptr=np.asarray(part_ptr, dtype=np.int32), G=G, E=E, sep_idx=sidx, schur=schur, g=g, u=u)
     out.C = Cs
-    out.Lc, out.Lr = (Lc, Lr) if banded else (None, None)
     return out
 
 
@@ -404,7 +356,7 @@ def _schur_sparse(level: Substructure, A_level: sp.spmatrix) -> sp.csr_matrix:
     return (0.5 * (S + S.T)).tocsr()
 
 
-def build_substructure_levels(A: sp.spmatrix, ptrs, gauge: bool = True, banded_leaf: bool = False) -> List[Substructure]:
+def build_substructure_levels(A: sp.spmatrix, ptrs, gauge: bool = True) -> List[Substructure]:
     """Factors of a dissection with ``len(ptrs)`` levels (pointer arrays as `substructure_order3` returns them): level
     k is `build_substructure` applied to level k - 1's Schur complement, the gauge functional is handed down as weights,
     only the last level forms its Schur complement densely; every level carries its sparse ``coupling`` block.
@@ -414,8 +366,7 @@ def build_substructure_levels(A: sp.spmatrix, ptrs, gauge: bool = True, banded_l
     levels, weights, offset = [], (None if gauge else np.zeros(A_level.shape[0])), 0
     for k, ptr in enumerate(ptrs):
         last = k == len(ptrs) - 1
-        lv = build_substructure(A_level, np.asarray(ptr, dtype=np.int64) - offset, weights=weights, with_schur=last,
-                                banded=banded_leaf and k == 0)
+        lv = build_substructure(A_level, np.asarray(ptr, dtype=np.int64) - offset, weights=weights, with_schur=last)
         nI = lv.n_interior
         lv.coupling = A_level[nI:, :nI].tocsr()
         levels.append(lv)

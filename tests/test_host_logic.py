@@ -1507,46 +1507,3 @@ def test_native_delaunay_never_returns_an_illegal_triangulation_on_hostile_cloud
         # or onto their edge); only coinciding points are left out, and exactly then the status says so
         assert len(np.unique(tri)) == distinct, (case, status)
         assert (status == _mesh_lib.OK) == (distinct == n), (case, status)
-
-
-def test_banded_leaf_factors_reproduce_the_dense_inverses():
-    """`substructure.band_factors` / `pack_leaf_banded` (the arrays of `tdgl_substructure_banded`): per part the banded
-    Cholesky factor in both orientations, walked exactly as the wavefront kernels walk it -- column-oriented forward
-    substitution, row-oriented backward substitution, reciprocal diagonals in entry 0 -- gives G_p b to round-off on
-    every part of a two-level dissection of a 5.8k-site mesh; bandwidths stay within the kernels' 64 lanes."""
-    from helpers import synthetic_mesh
-    from tdgl_amd.hipcore import poisson_matrix, rcm_permutation
-    from tdgl_amd.substructure import build_substructure_levels, pack_leaf_banded, substructure_order2
-
-    mesh = synthetic_mesh(70)
-    n, em = len(mesh.sites), mesh.edge_mesh
-    perm = rcm_permutation(em.edges, n)
-    rank = np.empty(n, dtype=np.int64)
-    rank[perm] = np.arange(n)
-    p, p1, p2 = substructure_order2(np.asarray(mesh.sites), em.edges, 60, 500, rank_hint=rank)
-    ip = np.empty(n, dtype=np.int64)
-    ip[p] = np.arange(n)
-    A = poisson_matrix(em.edges.astype(np.int64), em.dual_edge_lengths / em.edge_lengths, n, ip)
-    levels = build_substructure_levels(A, [p1, p2], banded_leaf=True)
-    pk = pack_leaf_banded(levels[0], True)
-    assert pk is not None and pk["n_parts"] == levels[0].n_parts and 4 <= pk["band_w"].max() <= 32
-    assert pk["is_indptr"][-1] == levels[0].coupling.nnz and pk["gauge"] == 1
-    rng = np.random.default_rng(0)
-    for q in range(0, pk["n_parts"], 7):
-        a, b = int(levels[0].part_ptr[q]), int(levels[0].part_ptr[q + 1])
-        m, w, off = b - a, int(pk["band_w"][q]), int(pk["band_off"][q])
-        lc = pk["lc"][off:off + m * w].reshape(m, w)
-        lr = pk["lr"][off:off + m * w].reshape(m, w)
-        rhs = rng.standard_normal(m)
-        s = rhs.copy()
-        for i in range(m):
-            s[i] *= lc[i, 0]
-            for k in range(1, min(w, m - i)):
-                s[i + k] -= lc[i, k] * s[i]
-        for i in range(m - 1, -1, -1):
-            s[i] *= lr[i, 0]
-            for k in range(1, min(w, i + 1)):
-                s[i - k] -= lr[i, k] * s[i]
-        want = levels[0].G[q] @ rhs
-        assert np.abs(s - want).max() < 1e-12 * np.abs(want).max()
-        assert abs(s.sum() - levels[0].g[a:b] @ rhs) < 1e-11 * np.abs(want).sum()  # the gauge share: sum(y) = (G 1) . b
