@@ -125,8 +125,9 @@ class TDGLContext:
 
                     rank = np.empty(self.n, dtype=np.int64)
                     rank[perm] = np.arange(self.n)
-                    self._pd_order = substructure_order3(np.asarray(mesh.sites), em.edges, self.SUB2_BLOCK or 160,
-                                                         self.SUB2_SUPER or 4096, self.SUB3_BIG, rank_hint=rank)
+                    self._pd_order = substructure_order3(
+                        np.asarray(mesh.sites), em.edges, self.SUB2_BLOCK or self.PD_BLOCKS[0], self.SUB2_SUPER or self.PD_BLOCKS[1],
+                        self.PD_BLOCKS[2] if self.SUB3_BIG == 32768 else self.SUB3_BIG, rank_hint=rank)
                 elif self.direct_solve and self.DENSE_MAX_SITES < self.n <= self.SUB_MAX_SITES:
                     # mid-size meshes: the substructured direct mu solve wants "interiors part by part,
                     # then the separator" as the site order (substructure.py); inside a part the sites keep
@@ -240,6 +241,10 @@ class TDGLContext:
     # factors, and the context keeps the reverse Cuthill-McKee order (16-bit column offsets in the stencil kernels).
     PD_MAX_SITES = int(__import__("os").environ.get("TDGL_PD_MAX_SITES", "1300000"))
     PD_CHOICE = 0  # 0: by predicted cost, 1: always the factors, 2: never (tests / A-B runs)
+    # (part, super-block, super-super-block) sizes of the factors when they precondition: measured time of one application
+    # at 1M sites with the final kernels (tools/exp_pd_blocks.py) 160/4096/32768 409 us, 128/4096/32768 407, 128/3072/24576 389,
+    # 144/3072/24576 390 (and the shortest host set-up, 4.9 s), 112/3072/24576 398, 128/2048/16384 397, 128/3072/32768 390
+    PD_BLOCKS = (144, 3072, 24576)
 
     def build_poisson(self, rtol=1e-10, max_iter=500, nu=2, check_every=0,
                       edge_currents_every_step=True, max_coarse=600, smoother="chebyshev",

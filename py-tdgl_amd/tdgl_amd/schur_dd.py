@@ -67,7 +67,7 @@ def local_dissection(sites: np.ndarray, edges: np.ndarray, blocks=None):
 
     n = len(sites)
     if blocks is None:
-        blocks = (160, 4096, 32768)
+        blocks = (144, 3072, 24576)  # (`hipcore.TDGLContext.PD_BLOCKS`: the sizes measured best for the factors as preconditioner)
     b1, b2, b3 = blocks
     if n >= 6 * b3 // 2 and n >= 4 * b2:  # three levels need a handful of super-super-blocks
         perm, p1, p2, p3 = substructure_order3(sites, edges, b1, b2, b3)
