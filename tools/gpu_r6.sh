@@ -63,6 +63,20 @@ PY
     done
   done
   ;;
+symab)
+  # symmetric tiles on the first level (k_sub_down_sym) against whole blocks (TDGL_PD_SYM=0): factors forced, 1M
+  for V in 1 0; do
+    TDGL_PD_SYM=$V timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --mu-precond factors --late-steps 2000 > $OUT/BENCH_${TAG}_1M_sym$V.json 2> $OUT/${TAG}_sym$V.err
+    python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/BENCH_${TAG}_1M_sym$V.json"))
+    print("sym=$V", d["value"], d.get("roofline_precond"), "late", (d.get("late_window") or {}).get("value"), "sustained", (d.get("sustained") or {}).get("value"), "parity", (d.get("parity") or {}).get("max_err"), d["setup_s"].get("precond_direct"))
+except Exception as e:
+    print("sym=$V no line", e); print(open("$OUT/${TAG}_sym$V.err").read()[-1500:])
+PY
+  done
+  ;;
 *) echo "unknown stage $STAGE";;
 esac
 done
