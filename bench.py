@@ -576,6 +576,9 @@ def main():
             setup["mu_solver"] = "direct (dense pseudo-inverse)"
         else:
             setup["mu_solver"] = "amg_pcg"
+        if st.get("substructure_error"):  # factors that were attempted and refused: the line must say what runs instead, and why
+            setup["substructure_error"] = str(st["substructure_error"])[:300]
+            log(f"rank {rank}: the nested-dissection factors were refused ({setup['substructure_error']}); mu solver: {setup['mu_solver']}")
         pd = getattr(ctx, "precond_direct", None)
         if pd:  # 0.65 - 1.3M sites: the three-level factors in fp32 as a second preconditioner of the CG
             setup["precond_direct"] = dict(host=round(st.get("substructure_host", 0.0), 2), device=round(st.get("substructure_device", 0.0), 2), **pd)
@@ -961,7 +964,10 @@ def main():
         avg_ms = main_run.direct[1] / main_run.direct[0]
         roofline_precond = dict(
             bound="hbm", kernel="one application of the nested-dissection factors (fp32 storage) as preconditioner: k_pd_gather + "
-                                "k_sub_down_lanes x 3 + sparse couplings x 3 + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x 3 + k_pd_scatter",
+                                + " + ".join(f"{k} x {c}" if c > 1 else k for k, c in (
+                                    ("k_sub_down_sym", sum(bool(t) for t in pdi.get("symmetric_tiles", []))),
+                                    ("k_sub_down_lanes", 3 - sum(bool(t) for t in pdi.get("symmetric_tiles", [])))) if c > 0)
+                                + " + sparse couplings x 3 + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x 3 + k_pd_scatter",
             achieved=round(pdi["bytes_per_application"] / (avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
             frac=round(pdi["bytes_per_application"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), bytes_per_application=int(pdi["bytes_per_application"]),
             avg_application_ms=round(avg_ms, 5), samples=main_run.direct[0], event_pair_overhead_ms=round(main_run.ev_over, 5),

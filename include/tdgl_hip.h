@@ -328,7 +328,12 @@ int tdgl_poisson_set_substructure_coupling(tdgl_ctx *ctx, int32_t level, const i
  * second application (the same rule on the residual that is left; the CG restarts from the iterate with beta = 0).
  * tdgl_get_precond_direct_stats: out4 = {solves that began with the factors, CG iterations taken with the factors, solves
  * with the V-cycle alone, iterations taken with the V-cycle (hand-overs included)} since the last reset, out4d =
- * {t_apply_us, t_vcycle_us, decades per application observed, hand-overs since the last reset}. */
+ * {t_apply_us, t_vcycle_us, decades per application observed, hand-overs since the last reset}.
+ * With fp32 storage, a level whose parts all have at most 256 rows (and which has parts enough to fill the chip: 256) keeps
+ * only the 16 x 16 tiles on or below the diagonal of its symmetric G blocks -- 56 % of the entries at 144 rows -- and its way
+ * down uses every tile twice (k_sub_down_sym).  tdgl_get_precond_direct_layout: sym_rows3[k] = the rows of a part level k
+ * stages in LDS when it is stored that way, 0 when it keeps whole blocks.  (TDGL_PD_SYM=0 in the environment: whole blocks
+ * everywhere, for A/B measurements; =2: tiles also on levels of fewer than 256 parts, for tests on small meshes.) */
 int tdgl_poisson_set_substructure_precond(tdgl_ctx *ctx, const int32_t *site_map, int32_t fp32_storage, double *t_apply_us,
                                           double *t_vcycle_us);
 int tdgl_poisson_precond_choice(tdgl_ctx *ctx, int32_t mode);
@@ -366,6 +371,7 @@ int tdgl_poisson_schur_complement(tdgl_ctx *ctx, double *out);
 int tdgl_poisson_schur_finish(tdgl_ctx *ctx, const double *S, int32_t fp32_storage, double *t_apply_us, double *t_vcycle_us);
 int tdgl_poisson_set_precond_times(tdgl_ctx *ctx, double t_apply_us, double t_vcycle_us);
 int tdgl_get_precond_direct_stats(tdgl_ctx *ctx, int64_t *out4, double *out4d, int32_t reset);
+int tdgl_get_precond_direct_layout(tdgl_ctx *ctx, int32_t *sym_rows3);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
  * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep

@@ -507,8 +507,11 @@ class TDGLContext:
             return False
         self.setup_times["substructure_device"] = t_dev
         sym = lambda m: ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
-        entries = sum(g.size for lv in levels for g in lv.G) + sum(e.size for lv in levels for e in lv.E) + sym(levels[2].n_sep)
-        info = dict(levels=3, storage="fp32", parts=levels[0].n_parts, separator=levels[0].n_sep, super_blocks=levels[1].n_parts,
+        tiles = self.precond_direct_layout()  # per level: G blocks as 16 x 16 tiles on or below the diagonal?
+        tri = lambda m: ((m + 15) // 16) * (((m + 15) // 16) + 1) // 2 * 256
+        entries = (sum((tri(g.shape[0]) if tiles[k] else g.size) for k, lv in enumerate(levels) for g in lv.G)
+                   + sum(e.size for lv in levels for e in lv.E) + sym(levels[2].n_sep))
+        info = dict(levels=3, storage="fp32", symmetric_tiles=[bool(t) for t in tiles], parts=levels[0].n_parts, separator=levels[0].n_sep, super_blocks=levels[1].n_parts,
                     top_separator=levels[1].n_sep, super_super_blocks=levels[2].n_parts, top_top_separator=levels[2].n_sep,
                     bytes_per_application=int(4 * entries + 12 * sum(lv.coupling.nnz for lv in levels) + 2 * 20 * self.n),
                     t_apply_us=round(ta.value, 1), t_vcycle_us=round(tv.value, 1))
@@ -579,9 +582,12 @@ class TDGLContext:
         self._chk(self._lib.tdgl_poisson_set_precond_times(self._ctx, float(times[0]), float(times[1])))
         self._chk(self._lib.tdgl_poisson_precond_choice(self._ctx, int(self.PD_CHOICE if choice is None else choice)))
         self.setup_times["substructure_device"] = t_dev
-        entries = sum(g.size for lv in levels for g in lv.G) + sum(e.size for lv in levels for e in lv.E)
+        tiles = self.precond_direct_layout()
+        tri = lambda m: ((m + 15) // 16) * (((m + 15) // 16) + 1) // 2 * 256
+        entries = (sum((tri(g.shape[0]) if tiles[k] else g.size) for k, lv in enumerate(levels) for g in lv.G)
+                   + sum(e.size for lv in levels for e in lv.E))
         self.precond_direct = dict(
-            kind="rank-level nested dissection", levels=len(levels), storage="fp32", interior=int(piece.n_interior), interface=ng,
+            kind="rank-level nested dissection", levels=len(levels), storage="fp32", symmetric_tiles=[bool(t) for t in tiles[:len(levels)]], interior=int(piece.n_interior), interface=ng,
             interface_owned=int(len(keep["gl"])), parts=levels[0].n_parts, separator=levels[0].n_sep,
             bytes_per_application=int(2 * (4 * entries + 12 * sum(lv.coupling.nnz for lv in levels)) + 4 * ng * ng // 2
                                       + 12 * (piece.A_GI.nnz + piece.A_IG.nnz)),
@@ -596,6 +602,13 @@ class TDGLContext:
         self._chk(self._lib.tdgl_get_precond_direct_stats(self._ctx, o4, o3, int(bool(reset))))
         return dict(solves_factors=int(o4[0]), iterations_factors=int(o4[1]), solves_vcycle=int(o4[2]), iterations_vcycle=int(o4[3]),
                     handovers=int(o3[3]), t_apply_us=round(o3[0], 1), t_vcycle_us=round(o3[1], 1), decades_per_application=round(o3[2], 2))
+
+    def precond_direct_layout(self):
+        """Per level of the fp32-stored factors: the rows of a part its way down stages when the level keeps only the
+        tiles on or below the diagonal of its G blocks (`tdgl_get_precond_direct_layout`), 0 for whole blocks."""
+        out = (C.c_int32 * 3)()
+        self._chk(self._lib.tdgl_get_precond_direct_layout(self._ctx, out))
+        return [int(v) for v in out]
 
     def precond_choice(self, mode: int):
         """0: the library chooses per solve by predicted cost, 1: always the factors, 2: always the AMG V-cycle."""

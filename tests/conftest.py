@@ -112,15 +112,18 @@ def three_level_solve(two_level_solve, monkeypatch):
     return 60
 
 
-@pytest.fixture
-def precond_direct_solve(three_level_solve, monkeypatch):
+@pytest.fixture(params=["symmetric_tiles", "whole_blocks"])
+def precond_direct_solve(request, three_level_solve, monkeypatch):
     """Every mesh from 200 sites up carries the three-level factors as the CG's PRECONDITIONER (fp32 storage, the
     context in reverse Cuthill-McKee order: `tdgl_poisson_set_substructure_precond`), which the product does between
     `SUB2_MAX_SITES` and `PD_MAX_SITES` (0.4 - 1.3 million sites) -- and every solve uses them (`PD_CHOICE` 1; the
-    product lets the library choose per solve)."""
+    product lets the library choose per solve).  Twice: with the G blocks of every level of small parts stored as the
+    16 x 16 tiles on or below their diagonal (what the product's first level is at those sizes; `TDGL_PD_SYM=2` extends
+    it to the few parts of a test mesh) and with whole blocks everywhere."""
     from tdgl_amd.hipcore import TDGLContext
 
+    monkeypatch.setenv("TDGL_PD_SYM", "2" if request.param == "symmetric_tiles" else "0")
     monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", 199)
     monkeypatch.setattr(TDGLContext, "PD_MAX_SITES", 10 ** 9)
     monkeypatch.setattr(TDGLContext, "PD_CHOICE", 1)
-    return 60
+    return request.param

@@ -128,7 +128,7 @@ def test_multi_rank_run_matches_single_gpu(world, transport, tmp_path):
 
 
 @pytest.mark.parametrize("world,transport,choice", [(2, "gloo", 1), (3, "ipc", 1), (8, "ipc", 1), (3, "ipc", 0)])
-def test_rank_level_dissection_as_the_preconditioner_matches_single_gpu(world, transport, choice, tmp_path):
+def test_rank_level_dissection_as_the_preconditioner_matches_single_gpu(world, transport, choice, tmp_path, monkeypatch):
     """`tdgl_amd/schur_dd.py`, `csrc/schur.inc`: the cut between the ranks as the top level of a nested dissection --
     every rank holds the fp32-stored factors of its interior block, all hold the pseudo-inverse of the interface
     complement -- as the CG's second preconditioner in one-process-per-GPU mode.  12.7k sites on 2 / 3 / 8 ranks
@@ -137,6 +137,8 @@ def test_rank_level_dissection_as_the_preconditioner_matches_single_gpu(world, t
     of sums where the distributed AMG cycle needs two per iteration."""
     size, kw = (130, 95), dict(b=0.3)
     mesh, ref_res, ref = _single_gpu_reference(size, kw)
+    if world == 3:  # (the local G blocks as symmetric tiles, which a rank's few parts here would not get by themselves)
+        monkeypatch.setenv("TDGL_PD_SYM", "2")
     mp.spawn(_worker, args=(world, _free_port(), transport, str(tmp_path), True, size, kw,
                             dict(schur=True, schur_blocks=(60, 500, 3000), schur_choice=choice)), nprocs=world, join=True)
     got = np.load(os.path.join(tmp_path, f"dist_{transport}_{world}.npz"))
