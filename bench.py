@@ -948,7 +948,10 @@ def main():
         solve_bytes = int(sub["bytes_per_solve"]) if sub else nt * (nt + 1) // 2 * 128 * 128 * 8
         avg_ms = main_run.direct[1] / main_run.direct[0]
         roofline_direct = dict(
-            bound="hbm", kernel="direct mu solve: " + (f"k_sub_down x {sub['levels']} + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x {sub['levels']}" if sub and sub.get("levels", 1) >= 2 else
+            bound="hbm", kernel="direct mu solve: " + (" + ".join(f"{k} x {c}" if c > 1 else k for k, c in (
+                ("k_sub_down_sym", sum(bool(t) for t in sub.get("symmetric_tiles", []))),
+                ("k_sub_down", sub["levels"] - sum(bool(t) for t in sub.get("symmetric_tiles", [])))) if c > 0)
+                                                       + f" + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up x {sub['levels']}" if sub and sub.get("levels", 1) >= 2 else
                                                        "k_sub_down + k_dense_sym_tiles + k_dense_sym_finish + k_sub_up" if sub else
                                                        "k_dense_sym_tiles + k_dense_sym_finish"),
             achieved=round(solve_bytes / (avg_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",

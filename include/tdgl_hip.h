@@ -372,6 +372,12 @@ int tdgl_poisson_schur_finish(tdgl_ctx *ctx, const double *S, int32_t fp32_stora
 int tdgl_poisson_set_precond_times(tdgl_ctx *ctx, double t_apply_us, double t_vcycle_us);
 int tdgl_get_precond_direct_stats(tdgl_ctx *ctx, int64_t *out4, double *out4d, int32_t reset);
 int tdgl_get_precond_direct_layout(tdgl_ctx *ctx, int32_t *sym_rows3);
+/* The same storage for the direct SOLVE (fp64 factors; reference: the LU solve of tdgl/solver/solver.py:516): after every level
+ * has been described, symmetric_tiles != 0 repacks the fp64 pool of each level that qualifies (all parts <= 256 rows, >= 256
+ * parts) into tiles on or below the diagonal + -E^T rows on 64-byte lines and switches that level's way down to the tile
+ * kernel; the other levels are left as uploaded.  Not after tdgl_poisson_set_substructure_precond (which lays the pools out
+ * itself).  tdgl_get_precond_direct_layout reports the outcome. */
+int tdgl_poisson_set_substructure_layout(tdgl_ctx *ctx, int32_t symmetric_tiles);
 /* The same solve with every factor formed ON THE DEVICE from the hierarchy's level-0 matrix: the caller
  * passes index arrays only (host layer: substructure.plan_for_device).  Per part the interior block is
  * read from the resident SELL matrix and inverted by the batched form of the blocked symmetric sweep

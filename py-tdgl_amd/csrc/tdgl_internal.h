@@ -43,6 +43,13 @@ struct DevBuf {
         p = nullptr;
         n = 0;
     }
+    void take(DevBuf &other) {  // (this buffer's memory is freed, the other's becomes this one's)
+        release();
+        p = other.p;
+        n = other.n;
+        other.p = nullptr;
+        other.n = 0;
+    }
     hipError_t alloc(size_t count, bool zero = true) {
         release();
         n = count;

@@ -263,6 +263,7 @@ SIGNATURES = {
     "tdgl_poisson_set_precond_times": (C.c_int, [_CTX, C.c_double, C.c_double]),
     "tdgl_get_precond_direct_stats": (C.c_int, [_CTX, C.POINTER(C.c_int64), c_f64p, C.c_int32]),
     "tdgl_get_precond_direct_layout": (C.c_int, [_CTX, C.POINTER(C.c_int32)]),
+    "tdgl_poisson_set_substructure_layout": (C.c_int, [_CTX, C.c_int32]),
     "tdgl_poisson_build_substructure": (C.c_int, [_CTX, C.POINTER(SubstructurePlan), c_f64p]),
     "tdgl_set_halo_plan": (C.c_int, [_CTX, C.POINTER(HaloPlan)]),
     "tdgl_set_deep_halo_plan": (C.c_int, [_CTX, C.POINTER(DeepHaloPlan)]),

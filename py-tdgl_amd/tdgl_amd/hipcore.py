@@ -362,13 +362,17 @@ class TDGLContext:
                     self.setup_times["substructure_error"] = repr(exc)
                     return False
             status, t_dev = self._upload_levels(levels, packed)
+            tiles = [0, 0, 0]
+            if status == _lib.TDGL_OK:
+                status, tiles = self._compact_direct_factors()
             sec = C.c_double(t_dev)
             sym = lambda m: 8 * ((m + 127) // 128) * (((m + 127) // 128) + 1) // 2 * 128 * 128
             info = dict(levels=3, sparse_separator_rhs=True, parts=levels[0].n_parts, separator=levels[0].n_sep,
                         super_blocks=levels[1].n_parts, top_separator=levels[1].n_sep, super_super_blocks=levels[2].n_parts,
-                        top_top_separator=levels[2].n_sep, built_on="host",
+                        top_top_separator=levels[2].n_sep, built_on="host", symmetric_tiles=[bool(t) for t in tiles],
                         bytes_per_solve=int(sum(8 * g.size for lv in levels for g in lv.G) + sum(8 * e.size for lv in levels for e in lv.E)
-                                            + 12 * sum(lv.coupling.nnz for lv in levels) + sym(levels[2].n_sep)))
+                                            + 12 * sum(lv.coupling.nnz for lv in levels) + sym(levels[2].n_sep)
+                                            - self._tile_savings([lv.G for lv in levels], tiles)))
             del levels, packed
         elif self._sub_super_ptr is not None:
             # two levels: the factors of both are formed on the host, the top separator's pseudo-inverse on the device
@@ -396,12 +400,16 @@ class TDGLContext:
                                                                               p_f64(keep_c[2]))
                     if status != _lib.TDGL_OK:
                         break
+            tiles = [0, 0, 0]
+            if status == _lib.TDGL_OK:
+                status, tiles = self._compact_direct_factors()
             sec = C.c_double(t_dev)
             info = dict(levels=2, sparse_separator_rhs=bool(sparse_sep), parts=sub2.outer.n_parts, separator=sub2.outer.n_sep, super_blocks=sub2.inner.n_parts,
-                        top_separator=sub2.inner.n_sep, built_on="host",
+                        top_separator=sub2.inner.n_sep, built_on="host", symmetric_tiles=[bool(t) for t in tiles[:2]],
                         bytes_per_solve=sub2.bytes_per_solve() - (0 if not sparse_sep else sum(
                             8 * e.size for lv in (sub2.outer, sub2.inner) for e in lv.E) - 12 * (
-                                sub2.outer.coupling.nnz + sub2.inner.coupling.nnz)))
+                                sub2.outer.coupling.nnz + sub2.inner.coupling.nnz))
+                        - self._tile_savings([sub2.outer.G, sub2.inner.G], tiles))
             del sub2, pk_o, pk_i
         elif not os.environ.get("TDGL_SUB_HOST"):
             # the factors are formed on the device; the host only describes the structure
@@ -444,6 +452,21 @@ class TDGLContext:
         if self.n >= self.DIRECT_SWITCH_MIN_SITES:
             self.direct_switching(True)
         return True
+
+    # the direct solve's levels of many small parts keep their symmetric G blocks as tiles on or below the diagonal
+    # (`tdgl_poisson_set_substructure_layout`; False: whole blocks, the form of the earlier rounds)
+    SUB_SYM_TILES = True
+
+    def _compact_direct_factors(self):
+        """After every level of a host-built direct solve has been uploaded: `(status, rows staged per level or 0)`."""
+        status = self._lib.tdgl_poisson_set_substructure_layout(self._ctx, int(bool(self.SUB_SYM_TILES)))
+        return status, (self.precond_direct_layout() if status == _lib.TDGL_OK else [0, 0, 0])
+
+    @staticmethod
+    def _tile_savings(G_by_level, tiles) -> int:
+        """Bytes per solve a level stored as fp64 tiles on or below the diagonal does not stream."""
+        tri = lambda m: ((m + 15) // 16) * (((m + 15) // 16) + 1) // 2 * 256
+        return int(sum(8 * (g.size - tri(g.shape[0])) for k, Gs in enumerate(G_by_level) if tiles[k] for g in Gs))
 
     def _upload_levels(self, levels, packed):
         """The factors of a multi-level dissection (`substructure.build_substructure_levels`, `pack_for_device(..., True)`)

@@ -86,19 +86,23 @@ def substructured_solve(monkeypatch):
     return 150
 
 
-@pytest.fixture
-def two_level_solve(monkeypatch):
+@pytest.fixture(params=["symmetric_tiles", "whole_blocks"])
+def two_level_solve(request, monkeypatch):
     """Every mesh from 200 sites up takes the TWO-level substructured direct mu solve (parts of ~60 sites inside
-    super-blocks of ~500), which the product uses between `SUB_MAX_SITES` and `SUB2_MAX_SITES`."""
+    super-blocks of ~500), which the product uses between `SUB_MAX_SITES` and `SUB2_MAX_SITES`.  Twice: with the G blocks
+    of every level of small parts stored as the 16 x 16 tiles on or below their diagonal (what the product's first level
+    is from a few tens of thousands of sites on; `TDGL_PD_SYM=2` extends it to the few parts of a test mesh) and with
+    whole blocks everywhere (`TDGL_PD_SYM=0`).  Returns which."""
     from tdgl_amd.hipcore import TDGLContext
 
+    monkeypatch.setenv("TDGL_PD_SYM", "2" if request.param == "symmetric_tiles" else "0")
     monkeypatch.setattr(TDGLContext, "DENSE_MAX_SITES", 199)
     monkeypatch.setattr(TDGLContext, "SUB_MAX_SITES", 199)
     monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", 10 ** 9)
     monkeypatch.setattr(TDGLContext, "SUB2_BLOCK", 60)
     monkeypatch.setattr(TDGLContext, "SUB2_SUPER", 500)
     monkeypatch.setattr(TDGLContext, "SUB3_MIN_SITES", 10 ** 9)
-    return 60
+    return request.param
 
 
 @pytest.fixture
@@ -109,21 +113,18 @@ def three_level_solve(two_level_solve, monkeypatch):
 
     monkeypatch.setattr(TDGLContext, "SUB3_MIN_SITES", 200)
     monkeypatch.setattr(TDGLContext, "SUB3_BIG", 3000)
-    return 60
+    return two_level_solve
 
 
-@pytest.fixture(params=["symmetric_tiles", "whole_blocks"])
-def precond_direct_solve(request, three_level_solve, monkeypatch):
+@pytest.fixture
+def precond_direct_solve(three_level_solve, monkeypatch):
     """Every mesh from 200 sites up carries the three-level factors as the CG's PRECONDITIONER (fp32 storage, the
     context in reverse Cuthill-McKee order: `tdgl_poisson_set_substructure_precond`), which the product does between
     `SUB2_MAX_SITES` and `PD_MAX_SITES` (0.4 - 1.3 million sites) -- and every solve uses them (`PD_CHOICE` 1; the
-    product lets the library choose per solve).  Twice: with the G blocks of every level of small parts stored as the
-    16 x 16 tiles on or below their diagonal (what the product's first level is at those sizes; `TDGL_PD_SYM=2` extends
-    it to the few parts of a test mesh) and with whole blocks everywhere."""
+    product lets the library choose per solve).  With tiles and with whole blocks like `two_level_solve`; returns which."""
     from tdgl_amd.hipcore import TDGLContext
 
-    monkeypatch.setenv("TDGL_PD_SYM", "2" if request.param == "symmetric_tiles" else "0")
     monkeypatch.setattr(TDGLContext, "SUB2_MAX_SITES", 199)
     monkeypatch.setattr(TDGLContext, "PD_MAX_SITES", 10 ** 9)
     monkeypatch.setattr(TDGLContext, "PD_CHOICE", 1)
-    return request.param
+    return three_level_solve
