@@ -563,7 +563,8 @@ def main():
         if sub:  # mid-size meshes: substructured direct solve, factors formed on the device
             setup["substructure"] = dict(host=round(st.get("substructure_host", 0.0), 2), device=round(st.get("substructure_device", 0.0), 2),
                                          parts=sub["parts"], separator=sub["separator"], built_on=sub["built_on"],
-                                         mb_per_solve=round(sub["bytes_per_solve"] / 1e6, 1))
+                                         mb_per_solve=round(sub["bytes_per_solve"] / 1e6, 1),
+                                         **({"symmetric_tiles": sub["symmetric_tiles"]} if "symmetric_tiles" in sub else {}))
             setup["mu_solver"] = "direct (substructured: dense interior blocks + dense Schur complement)"
             if sub.get("levels", 1) >= 2:
                 setup["substructure"].update(levels=sub["levels"], super_blocks=sub["super_blocks"], top_separator=sub["top_separator"],
