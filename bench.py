@@ -462,7 +462,8 @@ def main():
                 # dissection's set-up, the meeting before a batch) run on a process group of ITS OWN, made here on the main
                 # thread: a collective still pending in a watchdog thread that was abandoned can then never pair with the
                 # main thread's next collective on the default group
-                cand_group = dist.new_group(backend="gloo") if world > 1 else None
+                with stdout_to_stderr():  # (gloo announces every new group's connections on stdout; stdout is the JSON line)
+                    cand_group = dist.new_group(backend="gloo") if world > 1 else None
 
                 def attempt(tr=tr, box=box, payload=payload, cand_group=cand_group):
                     try:

@@ -17,8 +17,8 @@ def _run(*flags, timeout=600):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout,
                        cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line on stdout
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]  # ONE JSON line on stdout, and nothing else
     return json.loads(lines[0])
 
 
