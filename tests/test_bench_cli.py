@@ -43,6 +43,27 @@ def test_two_ranks_sharing_the_gpu_race_the_transports_and_report_it():
     assert d["conservation"]["relative"] < 1e-7 and d["conservation"]["max_abs_current"] > 1e-3
 
 
+def test_under_the_drivers_launcher_all_ranks_together_print_one_line():
+    """The driver's literal multi-GPU command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- where EVERY rank's stdout is the launcher's: one
+    JSON line from rank 0 and not a byte more from anybody (gloo announces every new process group on stdout, RCCL prints
+    a banner: both are routed to stderr)."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "5",
+                        "--share-devices", "--workload", "60k", "--preroll", "45", "--no-cpu-baseline", "--config5", "off"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 5 and d["value"] > 0 and d["transport"]["used"] == "ipc"
+
+
 def test_eight_ranks_sharing_the_gpu_run_the_drivers_command_shape():
     """The driver's multi-GPU command with the rank count of the scaling run (`--gpus 8`), rehearsed on the one GPU there
     is: the peer-mapped transport passes its self-test on all eight ranks, RCCL's refusal of ranks that share a device is
