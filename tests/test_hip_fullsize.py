@@ -100,6 +100,7 @@ def test_config4_strip_500k_current_conservation_and_poisson_residual(mu_solver,
         # what ships at 501k sites: CG with two resident preconditioners -- the AMG V-cycle and three levels of nested
         # dissection stored in fp32 --, the cheaper one per solve; the context in reverse Cuthill-McKee order
         assert pd and pd["levels"] == 3 and pd["storage"] == "fp32" and pd["super_super_blocks"] >= 8 and sub is None and not ctx.dense_direct
+        assert pd["symmetric_tiles"] == [True, False, False], pd  # (the first level's 3,400 parts of ~125 rows: tiles)
     else:
         assert sub is None and pd is None and not ctx.dense_direct
     ctx.set_state(solver.psi_init, solver.mu_init)
@@ -186,6 +187,8 @@ def test_config2_250k_uniform_field_first_steps_match_oracle(mu_solver, request,
     want_levels = dict(amg_pcg=0, product_default=2, three_levels=3)[mu_solver]
     assert (0 if sub is None else sub["levels"]) == want_levels and (sub is None or sub["super_blocks"] > 40)
     assert want_levels < 3 or sub["super_super_blocks"] >= 6
+    # (the fp64 factors of the SOLVE as they ship: the first level's ~1,500 parts as tiles on or below the diagonal)
+    assert sub is None or (sub["symmetric_tiles"][0] and not any(sub["symmetric_tiles"][1:])), sub
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     res = ctx.run(12)
@@ -382,6 +385,7 @@ def test_config3_and_5_steps_satisfy_their_defining_equations(side, n_sites, ste
     solver = TDGLSolver.from_dimensionless(mesh, opts, uniform_field_A(mesh, 0.1), 1.0, U_DEFAULT, GAMMA_DEFAULT)
     ctx = solver.ctx
     assert (ctx.precond_direct is not None) == (mu_solver == "product_default")
+    assert ctx.precond_direct is None or ctx.precond_direct["symmetric_tiles"] == [True, False, False]
     ctx.set_state(solver.psi_init, solver.mu_init)
     ctx.begin_stage()
     res = ctx.run(steps)
