@@ -412,6 +412,7 @@ struct tdgl_ctx {
     // AMG V-cycle per solve, by predicted cost (iterations x measured time per application).
     bool sub_precond = false;
     bool sub_fp32 = false;
+    int sub_up_R[3] = {1, 1, 1};          // per level: chunks of 64 rows a workgroup of the way up takes (a whole part where > 1)
     int sub_sym_lds[3] = {0, 0, 0};       // per level: rows of b_p k_sub_down_sym stages (0: whole blocks, k_sub_down_lanes)
     bool sub_lanes = false;               // the ways down run k_sub_down_lanes (chunk lists rebuilt for it)
     bool sub_ident[3] = {false, false, false};  // level k's separator rows are their identity segment alone (out = b)
